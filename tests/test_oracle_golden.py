@@ -1,0 +1,84 @@
+"""Pin the CPU oracle (oracle/unet_oracle.py) against fixtures produced by the real
+reference (oracle/gen_golden.py).  Same stock torch ops in the same order -> expect 0.0;
+the asserted bound is 1e-6."""
+import os
+
+import torch
+
+from oracle import unet_oracle as O
+
+TOL = 1e-6
+
+
+def mad(a, b):
+    return (a - b).abs().max().item()
+
+
+def test_schedule_tables(golden):
+    for name in ("linear", "cosine"):
+        s = O.make_schedule(beta_schedule=name)
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "posterior_variance"):
+            assert torch.equal(s[k], golden[f"sched_{name}_{k}"]), (name, k)
+    s = O.make_schedule()
+    assert abs(s["alphas_cumprod"][0].item() - 0.99989998) < 1e-7
+    assert s["alphas_cumprod_prev"][0].item() == 1.0 and s["posterior_variance"][0].item() == 0.0
+
+
+def test_timesteps(golden):
+    assert torch.equal(O.make_timesteps(1000, 50), golden["timesteps_50"])
+    t30 = O.make_timesteps(1000, 30)
+    assert torch.equal(t30, golden["timesteps_30"]) and len(t30) == 31  # n does not divide T
+
+
+def test_forward_scalar_and_batched_t(golden, sd):
+    x = golden["fwd_x"]
+    with torch.no_grad():
+        for t in (0, 500, 999):
+            assert mad(O.unet_forward(sd, x, torch.tensor(t)), golden[f"fwd_eps_t{t}"]) <= TOL
+        assert mad(O.unet_forward(sd, x, golden["fwd_tb"]), golden["fwd_eps_tb"]) <= TOL
+        taps = {}
+        O.unet_forward(sd, x, torch.tensor(500), taps=taps)
+        assert mad(taps["temb"], golden["fwd_temb_t500"]) <= TOL
+        assert mad(taps["init"], golden["fwd_init"]) <= TOL
+        assert mad(taps["down1"], golden["fwd_down1_t500"]) <= TOL
+
+
+def test_ddim50_free_running(golden, sd):
+    rec = []
+    out = O.sample(sd, O.make_schedule(), (4, 1, 32, 32), 50, 0.0, x_T=golden["ddim50_x_T"], record=rec)
+    assert mad(out, golden["ddim50_out"]) <= 1e-5
+    for i, (t, x, e, xn) in enumerate(rec):
+        assert mad(e, golden["ddim50_es"][i]) <= 1e-5
+
+
+def test_ddim50_eta_noise_order(golden, sd):
+    # global-generator draw order: x_T, then one randn_like per step after the model call
+    torch.manual_seed(42)
+    out = O.sample(sd, O.make_schedule(), (2, 1, 32, 32), 50, 0.5)
+    assert mad(out, golden["ddim50eta_out"]) <= 1e-5
+
+
+def test_ancestral_teacher_forced(golden, sd):
+    sched = O.make_schedule()
+    steps = golden["anc1000_steps"]
+    with torch.no_grad():
+        for j, i in enumerate(steps.tolist()):
+            x = golden["anc1000_xs"][j]
+            e = O.unet_forward(sd, x, torch.tensor(i))
+            scale = max(1.0, golden["anc1000_es"][j].abs().max().item())
+            assert mad(e, golden["anc1000_es"][j]) <= 1e-6 * scale
+            if j + 1 < len(steps) and steps[j + 1] == i + 1:
+                xn = O.sampler_step(sched, e, torch.tensor(i), x, 1.0, golden["anc1000_noises_kept"][j])
+                assert mad(xn, golden["anc1000_xs"][j + 1]) <= 1e-6 * max(1.0, xn.abs().max().item())
+
+
+def test_ancestral20_free_running(golden, sd):
+    torch.manual_seed(7)
+    out = O.sample(sd, O.make_schedule(), (2, 1, 32, 32), 20, 1.0)
+    assert mad(out, golden["anc20_out"]) <= 1e-5 * max(1.0, out.abs().max().item())
+
+
+def test_class_conditioner(golden):
+    cd = torch.load(os.path.join(os.path.dirname(__file__), "golden", "classcond11_seed43.pth"),
+                    weights_only=True)
+    assert mad(O.class_conditioner(cd, golden["cc_labels"]), golden["cc_out"]) <= TOL
