@@ -1,0 +1,63 @@
+"""ctypes binding of libdm_sampler.so (C ABI: include/dm_sampler.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is NO
+fallback: if the shared object is missing, loading raises, and every op of this package
+fails loudly rather than running some other implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdm_sampler.so")
+
+_lib = None
+
+_vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+
+_SIGS = {
+    "dm_last_error": (C.c_char_p, []),
+    "dm_version": (_i, []),
+    "dm_unet_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i]),
+    "dm_unet_destroy": (None, [_vp]),
+    "dm_unet_packed_floats": (_sz, [_vp]),
+    "dm_unet_pack_weights": (_i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _vp]),
+    "dm_unet_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "dm_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "dm_time_embed": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "dm_sampler_step": (_i, [_vp, _vp, _vp, C.POINTER(_f), _vp, _sz, _vp]),
+    "dm_sampler_coefs": (_i, [_vp, _vp, _vp, _i, _vp, _i, _f, _vp]),
+    "dm_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _sz, _i, _vp]),
+    "dm_conv_packed_floats": (_sz, [_i, _i, _i]),
+    "dm_pack_conv_weight": (_i, [_i, _vp, _i, _i, _vp, _vp]),
+    "dm_conv_stats_partials": (_i, [_i, _i, _i]),
+    "dm_conv2d": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i, _vp, _vp,
+                       _i, _i, _i, _vp]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    """Map a non-zero return code to RuntimeError carrying the library's message."""
+    if rc != 0:
+        raise RuntimeError(lib().dm_last_error().decode())
+
+
+def ptr(t):
+    """Device/host pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,561 @@
+// dm_api.hip — C ABI (include/dm_sampler.h) and launch logic of libdm_sampler.so.
+// Host code: geometry selection, packed-weight layout, workspace carving, the UNet launch
+// sequence (diffusion/model.py:120-151), the sampling loop and its hipGraph capture
+// (diffusion/sampler.py:45-76,136-172).  No torch types; plain pointers and sizes.
+#include "dm_kernels.hip"
+#include "../../include/dm_sampler.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// ------------------------------------------------------------------ conv geometry
+struct ConvGeo {
+  int MT, th_log, tw_log, ni, tiles_x, tiles_per_img, hth, htw, Hb, Wb, pout, OH, OW;
+  float cnt_out;
+};
+
+// Tile shape depends on the layer's resolution only (never on B), so per-image results are
+// independent of the batch size and of how a batch is sharded over GPUs.
+ConvGeo conv_geo(int kind, int H, int W, int Cout) {
+  ConvGeo g;
+  g.Hb = (kind == 1) ? H / 2 : H;
+  g.Wb = (kind == 1) ? W / 2 : W;
+  g.OH = (kind == 0) ? H : (kind == 1) ? H / 2 : 2 * H;
+  g.OW = (kind == 0) ? W : (kind == 1) ? W / 2 : 2 * W;
+  const int npix = g.Hb * g.Wb;
+  g.MT = (kind == 1) ? 64 : (npix >= 256 ? 128 : 64);
+  int tw = g.Wb < ((kind == 1) ? 8 : 16) ? g.Wb : ((kind == 1) ? 8 : 16);
+  int th = g.Hb < g.MT / tw ? g.Hb : g.MT / tw;
+  g.ni = g.MT / (th * tw);
+  g.th_log = ilog2(th);
+  g.tw_log = ilog2(tw);
+  g.tiles_x = g.Wb / tw;
+  g.tiles_per_img = (g.Hb / th) * g.tiles_x;
+  const int s = (kind == 1) ? 2 : 1;
+  const int halo = (kind == 2) ? 1 : 2;
+  g.hth = th * s + halo;
+  g.htw = tw * s + halo;
+  g.pout = g.tiles_per_img * (kind == 2 ? 4 : 1);
+  g.cnt_out = (float)(th * tw) * (float)(Cout / DM_GROUPS);
+  return g;
+}
+
+struct ConvCall {
+  int kind;
+  const float* x1; int c1;
+  const float* x2; int c2;
+  const float* wp; const float* bias; int cout;
+  const float* stats_in; int pin; float cnt_in;
+  const float* gamma; const float* beta;
+  const float* temb; int temb_stride; int temb_step_stride;
+  const int* step_ptr; int step_off;
+  float* y; float* stats_out;
+  int B, H, W;
+};
+
+template <int MB, int KIND, int KC>
+int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_done = false;  // benign race: setting the attribute twice is harmless
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, KIND, KC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_mfma_kernel<MB, KIND, KC>), grid, dim3(256), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_conv(const ConvCall& c, hipStream_t s) {
+  const int cin = c.c1 + c.c2;
+  if (c.kind < 0 || c.kind > 2) return fail("conv: unknown kind %d", c.kind);
+  if (c.c1 % 64 || c.c2 % 64 || c.cout % 64) return fail("conv: channel counts must be multiples of 64 (got %d+%d -> %d)", c.c1, c.c2, c.cout);
+  if (c.cout != 64 && c.cout != 128 && c.cout != 256 && c.cout != 512 && c.stats_out)
+    return fail("conv: GroupNorm(8) statistics need Cout in {64,128,256,512} (got %d)", c.cout);
+  if (!is_pow2(c.H) || !is_pow2(c.W)) return fail("conv: spatial dims must be powers of two (got %dx%d)", c.H, c.W);
+  if (c.kind == 1 && (c.H < 2 || c.W < 2)) return fail("conv: stride-2 conv needs H,W >= 2");
+  if (c.stats_in && c.c2) return fail("conv: input transform and channel concat are exclusive");
+  if (c.B <= 0) return fail("conv: empty batch");
+  const ConvGeo g = conv_geo(c.kind, c.H, c.W, c.cout);
+  ConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.x1 = c.x1; a.x2 = c.x2; a.wp = c.wp; a.bias = c.bias; a.y = c.y;
+  a.stats_in = c.stats_in; a.gamma = c.gamma; a.beta = c.beta; a.temb = c.temb;
+  a.step_ptr = c.step_ptr; a.stats_out = c.stats_out; a.cnt_in = c.cnt_in; a.pin = c.pin;
+  a.temb_stride = c.temb_stride; a.temb_step_stride = c.temb_step_stride; a.step_off = c.step_off;
+  a.B = c.B; a.H = c.H; a.W = c.W; a.C1 = c.c1; a.C2 = c.c2; a.Cout = c.cout;
+  a.Hb = g.Hb; a.Wb = g.Wb; a.th_log = g.th_log; a.tw_log = g.tw_log; a.ni = g.ni;
+  a.tiles_x = g.tiles_x; a.tiles_per_img = g.tiles_per_img; a.hth = g.hth; a.htw = g.htw;
+  a.mg_htw = (unsigned)((0x100000000ull + g.htw - 1) / g.htw);
+  a.mg_hth = (unsigned)((0x100000000ull + g.hth - 1) / g.hth);
+  a.pout = g.pout;
+  const int kc = (c.kind == 1) ? 32 : 64;
+  const size_t np = (size_t)g.ni * g.hth * g.htw;
+  size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0);
+  const size_t epi_f = (size_t)g.MT * 8 + 64;
+  if (lds_f < epi_f) lds_f = epi_f;
+  const size_t lds = lds_f * sizeof(float);
+  if (lds > 160 * 1024) return fail("conv: tile needs %zu B of LDS (> 160 KiB)", lds);
+  const int groups = (c.B + g.ni - 1) / g.ni;
+  dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), c.kind == 2 ? 4u : 1u);
+  (void)cin;
+  if (c.kind == 0) return g.MT == 128 ? launch_conv_t<2, 0, 64>(a, grid, lds, s) : launch_conv_t<1, 0, 64>(a, grid, lds, s);
+  if (c.kind == 2) return g.MT == 128 ? launch_conv_t<2, 2, 64>(a, grid, lds, s) : launch_conv_t<1, 2, 64>(a, grid, lds, s);
+  return launch_conv_t<1, 1, 32>(a, grid, lds, s);
+}
+
+size_t conv_packed_floats(int kind, int cin, int cout) {
+  const int taps = kind == 0 ? 9 : 16;  // KIND 2: 4 parities x 4 taps
+  return (size_t)taps * cin * cout;
+}
+
+int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream_t s) {
+  if (cin % 8 || cout % 32) return fail("pack_conv: cin %% 8 / cout %% 32");
+  const size_t total = conv_packed_floats(kind, cin, cout);
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind, w, cin, cout, out, total);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ model container
+struct BlockOff { size_t tmw, tmb, c1, c1b, c2, c2b, tr, trb, g1, b1, g2, b2; };
+
+struct GraphEntry {
+  const void *packed, *x, *ws, *coefs, *noise, *cond;
+  int B, H, W, S, cfg;
+  float guidance;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+struct dm_unet {
+  int Cin, Cout, C, E;
+  size_t o_freqs, o_tm1w, o_tm1b, o_tm2w, o_tm2b, o_initw, o_initb;
+  BlockOff blk[6];
+  size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb;
+  size_t total;
+  std::vector<GraphEntry> graphs;
+};
+
+namespace {
+
+struct Workspace {
+  float *A0, *T1, *T2, *D1, *D2, *D3, *BT0, *BT, *U1, *U2, *SA, *SB, *heads, *temb, *eps, *xx;
+  int* step;
+  size_t bytes;
+};
+
+// Carve the workspace for a denoiser batch B (all offsets 256-B aligned).
+Workspace carve(const dm_unet* m, void* base, int B, int H, int W, int nsteps) {
+  Workspace w;
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+    off += align_up(floats * sizeof(float), 256);
+    return p;
+  };
+  const size_t full = (size_t)B * H * W * m->C;
+  w.A0 = take(full);  // init_conv output; reused for up3's output (u3)
+  w.T1 = take(full);
+  w.T2 = take(full);
+  w.D1 = take(full / 4);
+  w.D2 = take(full / 16);
+  w.D3 = take(full / 64);
+  w.BT0 = take(full / 64);
+  w.BT = take(full / 64);
+  w.U1 = take(full / 16);
+  w.U2 = take(full / 4);
+  const size_t pmax = (size_t)H * W / 64 > 1 ? (size_t)H * W / 64 : 1;
+  w.SA = take((size_t)B * pmax * DM_GROUPS * 2);
+  w.SB = take((size_t)B * pmax * DM_GROUPS * 2);
+  const size_t nt = (size_t)(nsteps > B ? nsteps : B);
+  w.heads = take(nt * 6 * m->C);
+  w.temb = take(nt * m->E);
+  w.eps = take((size_t)B * m->Cout * H * W);
+  w.xx = take((size_t)B * m->Cin * H * W);
+  w.step = reinterpret_cast<int*>(take(64));
+  w.bytes = off;
+  return w;
+}
+
+int check_geometry(const dm_unet* m, int B, int H, int W) {
+  if (B <= 0) return fail("batch must be positive (got %d)", B);
+  if (!is_pow2(H) || !is_pow2(W) || H < 8 || W < 8)
+    return fail("image height/width must be powers of two >= 8 (three 2x down-samplings; got %dx%d)", H, W);
+  (void)m;
+  return 0;
+}
+
+int launch_time_embed(const dm_unet* m, const float* P, const int64_t* t, int nt, const float* cond,
+                      float* temb, float* heads, hipStream_t s) {
+  TimeArgs a;
+  a.freqs = P + m->o_freqs;
+  a.w1 = P + m->o_tm1w; a.b1 = P + m->o_tm1b; a.w2 = P + m->o_tm2w; a.b2 = P + m->o_tm2b;
+  for (int k = 0; k < 6; ++k) { a.hw[k] = P + m->blk[k].tmw; a.hb[k] = P + m->blk[k].tmb; }
+  a.t = t; a.cond = cond; a.temb = temb; a.heads = heads; a.E = m->E; a.C = m->C;
+  hipLaunchKernelGGL(time_embed_kernel, dim3((unsigned)nt), dim3(256), 3 * m->E * sizeof(float), s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// One denoiser evaluation (everything after the time embedding): model.py:135-151.
+// heads: [.., 6, C] table; heads_img_stride = 6*C when every image has its own timestep
+// (training-style [B] t) else 0; in the sampling loop the table is indexed by the step
+// (step_ptr/step_off, stride 6*C per step, or 6*C*B with per-image heads).
+int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, const float* heads,
+              int heads_img_stride, int heads_step_stride, const int* step_ptr, int step_off,
+              const Workspace& w, int B, int H, int W, hipStream_t s) {
+  const int C = m->C;
+  {  // init_conv (model.py:135)
+    const size_t lds = (size_t)m->Cin * 9 * C * sizeof(float);
+    const size_t total = (size_t)B * H * W * (C / 4);
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 65536u * 4) blocks = 65536u * 4;
+    hipLaunchKernelGGL(init_conv_kernel, dim3(blocks), dim3(256), lds, s, x, P + m->o_initw, P + m->o_initb, w.A0, B, m->Cin, H, W, C);
+    HIP_TRY(hipGetLastError());
+  }
+  ConvCall c;
+  auto base = [&](int kind, const float* x1, int c1, const float* x2, int c2, size_t wp, size_t bias, float* y, float* so, int h, int ww) {
+    memset(&c, 0, sizeof c);
+    c.kind = kind; c.x1 = x1; c.c1 = c1; c.x2 = x2; c.c2 = c2; c.wp = P + wp; c.bias = P + bias; c.cout = C;
+    c.y = y; c.stats_out = so; c.B = B; c.H = h; c.W = ww;
+  };
+  auto with_tf = [&](const float* si, int kind_prod, int hp, int wp_, size_t g, size_t b) {
+    const ConvGeo pg = conv_geo(kind_prod, hp, wp_, C);
+    c.stats_in = si; c.pin = pg.pout; c.cnt_in = pg.cnt_out; c.gamma = P + g; c.beta = P + b;
+  };
+  // Block.forward (model.py:52-64); in: block input(s) at hxw
+  auto block = [&](int k, const float* in1, const float* in2, int h, int ww, bool up, float* out, float* out_stats) -> int {
+    const BlockOff& o = m->blk[k];
+    base(0, in1, C, in2, in2 ? C : 0, o.c1, o.c1b, w.T1, w.SA, h, ww);
+    if (launch_conv(c, s)) return 1;
+    base(0, w.T1, C, nullptr, 0, o.c2, o.c2b, w.T2, w.SB, h, ww);
+    with_tf(w.SA, 0, h, ww, o.g1, o.b1);
+    c.temb = heads + (size_t)k * C; c.temb_stride = heads_img_stride; c.temb_step_stride = heads_step_stride;
+    c.step_ptr = step_ptr; c.step_off = step_off;
+    if (launch_conv(c, s)) return 1;
+    base(up ? 2 : 1, w.T2, C, nullptr, 0, o.tr, o.trb, out, out_stats, h, ww);
+    with_tf(w.SB, 0, h, ww, o.g2, o.b2);
+    return launch_conv(c, s);
+  };
+  if (block(0, w.A0, nullptr, H, W, false, w.D1, nullptr)) return 1;
+  if (block(1, w.D1, nullptr, H / 2, W / 2, false, w.D2, nullptr)) return 1;
+  if (block(2, w.D2, nullptr, H / 4, W / 4, false, w.D3, nullptr)) return 1;
+  // bottleneck (model.py:98-103,143)
+  base(0, w.D3, C, nullptr, 0, m->o_b0, m->o_b0b, w.BT0, w.SA, H / 8, W / 8);
+  if (launch_conv(c, s)) return 1;
+  base(0, w.BT0, C, nullptr, 0, m->o_b3, m->o_b3b, w.BT, nullptr, H / 8, W / 8);
+  with_tf(w.SA, 0, H / 8, W / 8, m->o_bg, m->o_bb);
+  if (launch_conv(c, s)) return 1;
+  // up path: channel concat [upstream, skip] (model.py:146-148) handled by two input pointers
+  if (block(3, w.BT, w.D3, H / 8, W / 8, true, w.U1, nullptr)) return 1;
+  if (block(4, w.U1, w.D2, H / 4, W / 4, true, w.U2, nullptr)) return 1;
+  if (block(5, w.U2, w.D1, H / 2, W / 2, true, w.A0, w.SA)) return 1;
+  {  // final_conv (model.py:111-115,151)
+    const ConvGeo pg = conv_geo(2, H / 2, W / 2, C);
+    const size_t lds = (size_t)(3 * C + m->Cout * C) * sizeof(float);
+    hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)(B * (H * W / 64))), dim3(256), lds, s, w.A0, w.SA, pg.pout,
+                       pg.cnt_out, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H * W, C, m->Cout);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+int launch_step(const float* x, const float* eps, const float* noise, const float* coefs_dev,
+                const int* step_ptr, int step_off, const float* cbyval, float* out, size_t count,
+                int cfg, float guidance, hipStream_t s) {
+  if (count % 4) return fail("sampler_step: element count must be a multiple of 4 (got %zu)", count);
+  StepArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.eps = eps; a.noise = noise; a.coefs = coefs_dev; a.step_ptr = step_ptr; a.out = out;
+  a.count = count; a.step_off = step_off; a.cfg = cfg; a.guidance = guidance;
+  if (cbyval) for (int i = 0; i < 5; ++i) a.c[i] = cbyval[i];
+  size_t blocks = (count / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+extern "C" {
+
+const char* dm_last_error(void) { return g_err.c_str(); }
+int dm_version(void) { return 1; }
+
+int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_channels, int time_emb_dim) {
+  if (!out) return fail("dm_unet_create: null out");
+  if (in_channels < 1 || in_channels > 4 || out_channels < 1 || out_channels > 4)
+    return fail("in/out channels must be in 1..4 (got %d, %d)", in_channels, out_channels);
+  if (model_channels != 64 && model_channels != 128 && model_channels != 256 && model_channels != 512)
+    return fail("model_channels must be one of 64, 128, 256, 512 (got %d)", model_channels);
+  if (time_emb_dim < 4 || time_emb_dim % 2 || time_emb_dim > 1024)
+    return fail("time_emb_dim must be even, in 4..1024 (got %d)", time_emb_dim);
+  dm_unet* m = new dm_unet();
+  m->Cin = in_channels; m->Cout = out_channels; m->C = model_channels; m->E = time_emb_dim;
+  const int C = m->C, E = m->E;
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
+  m->o_freqs = take(E / 2);
+  m->o_tm1w = take((size_t)E * E); m->o_tm1b = take(E); m->o_tm2w = take((size_t)E * E); m->o_tm2b = take(E);
+  m->o_initw = take((size_t)C * m->Cin * 9); m->o_initb = take(C);
+  for (int k = 0; k < 6; ++k) {
+    const bool up = k >= 3;
+    BlockOff& b = m->blk[k];
+    b.tmw = take((size_t)C * E); b.tmb = take(C);
+    b.c1 = take(conv_packed_floats(0, up ? 2 * C : C, C)); b.c1b = take(C);
+    b.tr = take(conv_packed_floats(up ? 2 : 1, C, C)); b.trb = take(C);
+    b.c2 = take(conv_packed_floats(0, C, C)); b.c2b = take(C);
+    b.g1 = take(C); b.b1 = take(C); b.g2 = take(C); b.b2 = take(C);
+  }
+  m->o_b0 = take(conv_packed_floats(0, C, C)); m->o_b0b = take(C);
+  m->o_bg = take(C); m->o_bb = take(C);
+  m->o_b3 = take(conv_packed_floats(0, C, C)); m->o_b3b = take(C);
+  m->o_fg = take(C); m->o_fb = take(C);
+  m->o_fw = take((size_t)m->Cout * C); m->o_fwb = take(m->Cout);
+  m->total = off;
+  *out = m;
+  return 0;
+}
+
+void dm_unet_destroy(dm_unet* m) {
+  if (!m) return;
+  for (auto& g : m->graphs) {
+    (void)hipGraphExecDestroy(g.exec);
+    (void)hipGraphDestroy(g.graph);
+  }
+  delete m;
+}
+
+size_t dm_unet_packed_floats(const dm_unet* m) { return m ? m->total : 0; }
+
+int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const float* freqs_dev,
+                         float* packed, void* stream) {
+  if (!m || !p || !packed) return fail("dm_unet_pack_weights: null argument");
+  if (nparams != DM_UNET_NUM_PARAMS) return fail("expected %d parameter tensors, got %d", DM_UNET_NUM_PARAMS, nparams);
+  for (int i = 0; i < nparams; ++i) if (!p[i]) return fail("parameter %d is null", i);
+  hipStream_t s = (hipStream_t)stream;
+  const int C = m->C, E = m->E;
+  auto copy = [&](size_t dst, const float* src, size_t n) -> int {
+    HIP_TRY(hipMemcpyAsync(packed + dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+  };
+  if (freqs_dev) {
+    if (copy(m->o_freqs, freqs_dev, E / 2)) return 1;
+  } else {
+    std::vector<float> f(E / 2);
+    const float sc = (float)(log(10000.0) / (E / 2 - 1));
+    for (int i = 0; i < E / 2; ++i) f[i] = expf((float)i * -sc);
+    HIP_TRY(hipMemcpy(packed + m->o_freqs, f.data(), f.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  int i = 0;
+  if (copy(m->o_tm1w, p[i++], (size_t)E * E) || copy(m->o_tm1b, p[i++], E) ||
+      copy(m->o_tm2w, p[i++], (size_t)E * E) || copy(m->o_tm2b, p[i++], E) ||
+      copy(m->o_initw, p[i++], (size_t)C * m->Cin * 9) || copy(m->o_initb, p[i++], C)) return 1;
+  auto do_block = [&](int k) -> int {
+    const bool up = k >= 3;
+    const BlockOff& b = m->blk[k];
+    if (copy(b.tmw, p[i++], (size_t)C * E) || copy(b.tmb, p[i++], C)) return 1;
+    if (pack_conv(0, p[i++], up ? 2 * C : C, C, packed + b.c1, s) || copy(b.c1b, p[i++], C)) return 1;
+    if (pack_conv(up ? 2 : 1, p[i++], C, C, packed + b.tr, s) || copy(b.trb, p[i++], C)) return 1;
+    if (pack_conv(0, p[i++], C, C, packed + b.c2, s) || copy(b.c2b, p[i++], C)) return 1;
+    if (copy(b.g1, p[i++], C) || copy(b.b1, p[i++], C) || copy(b.g2, p[i++], C) || copy(b.b2, p[i++], C)) return 1;
+    return 0;
+  };
+  for (int k = 0; k < 3; ++k) if (do_block(k)) return 1;
+  if (pack_conv(0, p[i++], C, C, packed + m->o_b0, s) || copy(m->o_b0b, p[i++], C) ||
+      copy(m->o_bg, p[i++], C) || copy(m->o_bb, p[i++], C) ||
+      pack_conv(0, p[i++], C, C, packed + m->o_b3, s) || copy(m->o_b3b, p[i++], C)) return 1;
+  for (int k = 3; k < 6; ++k) if (do_block(k)) return 1;
+  if (copy(m->o_fg, p[i++], C) || copy(m->o_fb, p[i++], C) ||
+      copy(m->o_fw, p[i++], (size_t)m->Cout * C) || copy(m->o_fwb, p[i++], m->Cout)) return 1;
+  if (i != DM_UNET_NUM_PARAMS) return fail("internal: consumed %d params", i);
+  return 0;
+}
+
+size_t dm_unet_workspace_bytes(const dm_unet* m, int B, int H, int W, int nsteps) {
+  if (!m || B <= 0 || H <= 0 || W <= 0) return 0;
+  return carve(m, nullptr, B, H, W, nsteps < 1 ? 1 : nsteps).bytes;
+}
+
+int dm_time_embed(dm_unet* m, const float* packed, const int64_t* t_dev, int nt, const float* cond_dev,
+                  float* temb_dev, float* heads_dev, void* stream) {
+  if (!m || !packed || !t_dev || !heads_dev) return fail("dm_time_embed: null argument");
+  if (nt <= 0) return fail("dm_time_embed: nt must be positive");
+  return launch_time_embed(m, packed, t_dev, nt, cond_dev, temb_dev, heads_dev, (hipStream_t)stream);
+}
+
+int dm_unet_forward(dm_unet* m, const float* packed, const float* x, const int64_t* t_dev, int nt,
+                    const float* cond_dev, float* eps, int B, int H, int W, void* ws, size_t ws_bytes,
+                    void* stream) {
+  if (!m || !packed || !x || !t_dev || !eps || !ws) return fail("dm_unet_forward: null argument");
+  if (check_geometry(m, B, H, W)) return 1;
+  if (nt != 1 && nt != B) return fail("timesteps must be 0-dim/[1] or [B] (got %d for batch %d)", nt, B);
+  Workspace w = carve(m, ws, B, H, W, 1);
+  if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes", ws_bytes, w.bytes);
+  hipStream_t s = (hipStream_t)stream;
+  if (launch_time_embed(m, packed, t_dev, nt, cond_dev, w.temb, w.heads, s)) return 1;
+  return unet_body(m, packed, x, eps, w.heads, nt == 1 ? 0 : 6 * m->C, 0, nullptr, 0, w, B, H, W, s);
+}
+
+int dm_sampler_step(const float* x, const float* eps, const float* noise, const float* coef_host,
+                    float* out, size_t count, void* stream) {
+  if (!x || !eps || !coef_host || !out) return fail("dm_sampler_step: null argument");
+  if (count == 0) return 0;
+  return launch_step(x, eps, noise, nullptr, nullptr, 0, coef_host, out, count, 0, 0.f, (hipStream_t)stream);
+}
+
+int dm_sampler_coefs(const float* acp, const float* acp_prev, const float* pv, int T,
+                     const int64_t* ts, int n, float eta, float* coefs) {
+  if (!acp || !acp_prev || !pv || !ts || !coefs) return fail("dm_sampler_coefs: null argument");
+  for (int i = 0; i < n; ++i) {
+    const int64_t t = ts[i];
+    if (t < 0 || t >= T) return fail("timestep %lld out of range [0,%d)", (long long)t, T);
+    float* c = coefs + (size_t)i * 8;
+    // fp32 arithmetic exactly as torch evaluates schedulers.py:118-128 on 0-dim tensors
+    c[0] = sqrtf(1.0f - acp[t]);
+    c[1] = sqrtf(acp[t]);
+    c[2] = sqrtf(acp_prev[t]);
+    c[3] = sqrtf(1.0f - acp_prev[t]);
+    c[4] = sqrtf(pv[t]) * eta;
+    c[5] = c[6] = c[7] = 0.f;
+  }
+  return 0;
+}
+
+int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, const int64_t* ts_dev,
+              const float* coefs_dev, int n, const float* noise_dev, const float* cond_dev, float guidance,
+              void* ws, size_t ws_bytes, int use_graph, void* stream) {
+  if (!m || !packed || !x || !ts_dev || !coefs_dev || !ws) return fail("dm_sample: null argument");
+  if (m->Cin != m->Cout) return fail("sampling needs in_channels == out_channels (got %d, %d)", m->Cin, m->Cout);
+  if (check_geometry(m, B, H, W)) return 1;
+  if (n <= 0) return fail("dm_sample: number of steps must be positive");
+  const int cfg = cond_dev ? 1 : 0;
+  const int Bd = cfg ? 2 * B : B;  // denoiser batch
+  Workspace w = carve(m, ws, Bd, H, W, n);
+  if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes", ws_bytes, w.bytes);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t count = (size_t)B * m->Cin * H * W;
+  if (cfg) return fail("dm_sample: classifier-free guidance is not implemented yet");
+  // Time embeddings of all n steps up front: they depend on t only.
+  if (launch_time_embed(m, packed, ts_dev, n, nullptr, nullptr, w.heads, s)) return 1;
+  const int hstep = 6 * m->C;
+
+  auto one_step = [&](const int* step_ptr, int step_off) -> int {
+    if (unet_body(m, packed, x, w.eps, w.heads, 0, hstep, step_ptr, step_off, w, Bd, H, W, s)) return 1;
+    return launch_step(x, w.eps, noise_dev, coefs_dev, step_ptr, step_off, nullptr, x, count, 0, guidance, s);
+  };
+
+  if (!use_graph) {
+    for (int i = 0; i < n; ++i) if (one_step(nullptr, i)) return 1;
+    return 0;
+  }
+  if (!s) return fail("dm_sample: graph capture needs a non-default stream");
+  hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(64), 0, s, w.step, 0);
+  HIP_TRY(hipGetLastError());
+  const int S0 = n < 50 ? n : 50;
+  auto get_graph = [&](int S, hipGraphExec_t* exec) -> int {
+    for (auto& g : m->graphs)
+      if (g.packed == packed && g.x == x && g.ws == ws && g.coefs == coefs_dev && g.noise == noise_dev &&
+          g.cond == cond_dev && g.B == B && g.H == H && g.W == W && g.S == S && g.cfg == cfg && g.guidance == guidance) {
+        *exec = g.exec;
+        return 0;
+      }
+    GraphEntry e;
+    e.packed = packed; e.x = x; e.ws = ws; e.coefs = coefs_dev; e.noise = noise_dev; e.cond = cond_dev;
+    e.B = B; e.H = H; e.W = W; e.S = S; e.cfg = cfg; e.guidance = guidance;
+    HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = 0;
+    for (int i = 0; i < S && !rc; ++i) rc = one_step(w.step, i);
+    if (!rc) {
+      hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, w.step, S);
+      if (hipGetLastError() != hipSuccess) rc = fail("advance_step launch failed");
+    }
+    hipError_t ce = hipStreamEndCapture(s, &e.graph);
+    if (rc) { if (ce == hipSuccess && e.graph) (void)hipGraphDestroy(e.graph); return 1; }
+    HIP_TRY(ce);
+    HIP_TRY(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+    if (m->graphs.size() >= 8) {
+      (void)hipGraphExecDestroy(m->graphs.front().exec);
+      (void)hipGraphDestroy(m->graphs.front().graph);
+      m->graphs.erase(m->graphs.begin());
+    }
+    m->graphs.push_back(e);
+    *exec = e.exec;
+    return 0;
+  };
+  hipGraphExec_t ex;
+  if (n / S0 > 0) {
+    if (get_graph(S0, &ex)) return 1;
+    for (int r = 0; r < n / S0; ++r) HIP_TRY(hipGraphLaunch(ex, s));
+  }
+  if (n % S0) {
+    if (get_graph(n % S0, &ex)) return 1;
+    HIP_TRY(hipGraphLaunch(ex, s));
+  }
+  return 0;
+}
+
+size_t dm_conv_packed_floats(int kind, int cin, int cout) { return conv_packed_floats(kind, cin, cout); }
+
+int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev, void* stream) {
+  if (!w_dev || !packed_dev) return fail("dm_pack_conv_weight: null argument");
+  if (kind < 0 || kind > 2) return fail("unknown conv kind %d", kind);
+  return pack_conv(kind, w_dev, cin, cout, packed_dev, (hipStream_t)stream);
+}
+
+int dm_conv_stats_partials(int kind, int H, int W) {
+  if (kind < 0 || kind > 2 || !is_pow2(H) || !is_pow2(W)) return 0;
+  return conv_geo(kind, H, W, 64).pout;
+}
+
+int dm_conv2d(int kind, const float* x1, int c1, const float* x2, int c2, const float* wp, const float* bias,
+              int cout, const float* stats_in, int pin, float cnt_in, const float* gamma, const float* beta,
+              const float* temb, int temb_stride, float* y, float* stats_out, int B, int H, int W, void* stream) {
+  if (!x1 || !wp || !bias || !y) return fail("dm_conv2d: null argument");
+  if (c2 && !x2) return fail("dm_conv2d: c2 > 0 but x2 is null");
+  if (stats_in && (!gamma || !beta || pin <= 0)) return fail("dm_conv2d: input transform needs gamma, beta, pin");
+  ConvCall c;
+  memset(&c, 0, sizeof c);
+  c.kind = kind; c.x1 = x1; c.c1 = c1; c.x2 = c2 ? x2 : nullptr; c.c2 = c2; c.wp = wp; c.bias = bias; c.cout = cout;
+  c.stats_in = stats_in; c.pin = pin; c.cnt_in = cnt_in; c.gamma = gamma; c.beta = beta;
+  c.temb = temb; c.temb_stride = temb_stride; c.y = y; c.stats_out = stats_out; c.B = B; c.H = H; c.W = W;
+  return launch_conv(c, (hipStream_t)stream);
+}
+
+}  // extern "C"

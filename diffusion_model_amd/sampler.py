@@ -1,0 +1,124 @@
+"""AncestralSampler / DDIMSampler / create_sampler drop-ins (reference: diffusion/sampler.py).
+
+``__call__`` keeps the reference's behaviour (ascending timesteps, a_{t-1} target, unused
+``prev_timestep`` — SURVEY F5) and its noise draw order (x_T, then one draw per step after the
+model call when eta > 0 — SURVEY F9), with the draws taken from the seeded CPU generator so a
+run reproduces the reference CPU sampler.  When the model is this package's UNetMini the whole
+loop runs inside libdm_sampler.so (dm_sample: time-embedding table, per-step UNet + fused
+update, captured in a hipGraph); any other callable model is driven step by step.
+"""
+from typing import Tuple
+
+import torch
+import tqdm
+
+from . import _lib
+from .model import UNetMini
+
+
+class _SamplerBase:
+    _desc = "Sampling"
+
+    def _init(self, scheduler, num_inference_steps, eta):
+        self.scheduler = scheduler
+        self.num_inference_steps = num_inference_steps
+        self.eta = eta
+        self.scheduler.set_timesteps(num_inference_steps)  # mutates the caller's scheduler, as the reference
+        self.device = self.scheduler.device
+        self.use_graph = True
+
+    def _draw(self, shape, n):
+        """Host draws in the reference's order."""
+        x_T = torch.randn(shape)
+        noises = torch.randn((n,) + tuple(shape)) if self.eta > 0 else None
+        return x_T, noises
+
+    def sample_from(self, model, x_T, noises=None, progress_bar=False):
+        """Run the loop from given x_T (and per-step noises [n,*shape] when eta > 0)."""
+        timesteps = self.scheduler.timesteps
+        n = timesteps.numel()
+        if self.eta > 0 and noises is None:
+            raise RuntimeError("eta > 0 needs per-step noise")
+        if isinstance(model, UNetMini):
+            return self._fused(model, x_T, noises if self.eta > 0 else None, timesteps)
+        x = x_T.to(self.device)
+        it = tqdm.tqdm(timesteps, desc=self._desc) if progress_bar else timesteps
+        for i, t in enumerate(it):
+            with torch.no_grad():
+                eps = model(x, t)
+            nz = noises[i] if self.eta > 0 else None
+            x = self.scheduler.step(eps, t, x, eta=self.eta, noise=nz)
+        return x
+
+    def _fused(self, model, x_T, noises, timesteps):
+        dev = model.packed_weights().device
+        B, Cin, H, W = x_T.shape
+        n = timesteps.numel()
+        x = x_T.to(dev, torch.float32).contiguous().clone()
+        ts_dev = timesteps.to(dev, torch.int64).contiguous()
+        coefs = self.scheduler.step_coefs(timesteps, self.eta).to(dev)
+        nz = None if noises is None else noises.to(dev, torch.float32).contiguous()
+        ws = model.workspace(B, H, W, n)
+        packed = model.packed_weights()
+        cur = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            _lib.check(_lib.lib().dm_sample(
+                model._native(), _lib.ptr(packed), _lib.ptr(x), B, H, W, _lib.ptr(ts_dev), _lib.ptr(coefs), n,
+                _lib.ptr(nz), None, 0.0, _lib.ptr(ws), ws.numel(), 1 if self.use_graph else 0, side.cuda_stream))
+        cur.wait_stream(side)
+        for t_ in (x, ts_dev, coefs, nz, ws, packed):
+            if t_ is not None:
+                t_.record_stream(side)
+        return x
+
+    def __call__(self, model, shape: Tuple[int, ...], progress_bar: bool = True):
+        """diffusion/sampler.py:45-76 / 136-172.  ``progress_bar`` is accepted; the fused loop
+        is one graph launch per <= 50 steps, so no per-step bar is shown for UNetMini."""
+        x_T, noises = self._draw(shape, self.scheduler.timesteps.numel())
+        return self.sample_from(model, x_T, noises, progress_bar)
+
+
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """hipGraph capture is illegal on the legacy default stream: the loop runs on a side stream."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
+class AncestralSampler(_SamplerBase):
+    """diffusion/sampler.py:8-76."""
+    _desc = "Ancestral Sampling"
+
+    def __init__(self, scheduler, num_inference_steps: int = 1000, eta: float = 1.0):
+        self._init(scheduler, num_inference_steps, eta)
+
+    def step(self, model_output, timestep, sample, noise=None):
+        return self.scheduler.step(model_output, timestep, sample, eta=self.eta, noise=noise)
+
+
+class DDIMSampler(_SamplerBase):
+    """diffusion/sampler.py:79-172."""
+    _desc = "DDIM Sampling"
+
+    def __init__(self, scheduler, num_inference_steps: int = 50, eta: float = 0.0):
+        self._init(scheduler, num_inference_steps, eta)
+
+    def step(self, model_output, timestep, sample, prev_timestep=None, noise=None):
+        # prev_timestep is accepted and ignored, exactly like the reference (sampler.py:117-118)
+        return self.scheduler.step(model_output, timestep, sample, eta=self.eta, noise=noise)
+
+
+def create_sampler(sampler_type: str, scheduler, **kwargs):
+    """diffusion/sampler.py:175-192."""
+    if sampler_type == "ancestral":
+        return AncestralSampler(scheduler, **kwargs)
+    elif sampler_type == "ddim":
+        return DDIMSampler(scheduler, **kwargs)
+    else:
+        raise ValueError(f"Unknown sampler type: {sampler_type}")

@@ -1,0 +1,129 @@
+/*
+ * dm_sampler.h — C ABI of libdm_sampler.so: MI355X (gfx950) reverse-diffusion sampling.
+ *
+ * The reference (dj-shark31/diffusion_model) is pure Python/PyTorch and has no FFI layer
+ * (SURVEY 8(b)); its hot path sits behind the Python classes UNetMini / DDPMScheduler /
+ * AncestralSampler / DDIMSampler.  This header is the boundary a binding (ctypes here,
+ * see diffusion_model_amd/_lib.py and INTEGRATION.md) uses to replace the tensor work
+ * inside those classes.  Every entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *  - All pointers named *_dev are device (HBM) pointers, fp32 unless said otherwise;
+ *    *_host are host pointers.  `stream` is a hipStream_t passed as void* (NULL = default).
+ *  - No entry point allocates device memory or synchronises, except dm_unet_create /
+ *    dm_unet_destroy (host-only state) and graph instantiation inside dm_sample.
+ *  - Return value: 0 on success, non-zero on error; dm_last_error() returns the message
+ *    (thread-local).  Shape/argument errors map to the RuntimeError/ValueError the
+ *    reference's torch ops would raise (host side re-raises).
+ *  - Activations inside the library are NHWC fp32 ("pixel-major": one pixel's channels
+ *    are contiguous).  Images at the boundary (x, eps) are NCHW exactly like the reference.
+ */
+#ifndef DM_SAMPLER_H
+#define DM_SAMPLER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dm_unet dm_unet; /* opaque: geometry + packed-weight offsets + graph cache */
+
+/* Number of parameter tensors of UNetMini in state_dict order (diffusion/model.py:82-115;
+ * key list in SURVEY 8(a) row M0): 4 time_mlp + 2 init_conv + 6 blocks x 12 + 6 bottleneck
+ * + 4 final_conv = 88. */
+#define DM_UNET_NUM_PARAMS 88
+
+const char* dm_last_error(void);
+int dm_version(void);
+
+/* ---- model container: replaces UNetMini.__init__ (diffusion/model.py:72-118) ---------- */
+int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_channels,
+                   int time_emb_dim);
+void dm_unet_destroy(dm_unet* m);
+
+/* Size (in floats) of the packed weight blob for this geometry. */
+size_t dm_unet_packed_floats(const dm_unet* m);
+
+/* Repack the 88 parameter tensors (device pointers, torch layouts: Conv2d OIHW,
+ * ConvTranspose2d IOHW, Linear [out,in]) into the kernels' layout (MFMA B-fragment order
+ * for the conv weights).  `freqs_dev` = the time_emb_dim/2 sinusoid frequencies
+ * exp(-i*ln(1e4)/(half-1)) (diffusion/model.py:19-21) or NULL to have the library compute
+ * them.  Re-run whenever the parameters change (EMA swap, load_state_dict). */
+int dm_unet_pack_weights(dm_unet* m, const float* const* params_dev, int nparams,
+                         const float* freqs_dev, float* packed_dev, void* stream);
+
+/* Workspace bytes needed by dm_unet_forward / dm_sample for batch B of HxW images and a
+ * time-step table of `nsteps` entries (1 for a single forward). */
+size_t dm_unet_workspace_bytes(const dm_unet* m, int B, int H, int W, int nsteps);
+
+/* ---- denoiser forward: replaces UNetMini.forward (diffusion/model.py:120-151) ---------
+ * x_dev [B,Cin,H,W] NCHW, t_dev int64[nt] with nt==1 (0-dim timestep, sampler.py:71,167)
+ * or nt==B (training-style, train.py:116-125).  cond_dev: optional [nt,E] embedding added
+ * to the time embedding (build-defined class conditioning hook) or NULL.  eps_dev [B,Cout,H,W]. */
+int dm_unet_forward(dm_unet* m, const float* packed_dev, const float* x_dev,
+                    const int64_t* t_dev, int nt, const float* cond_dev, float* eps_dev,
+                    int B, int H, int W, void* workspace_dev, size_t workspace_bytes,
+                    void* stream);
+
+/* ---- time embedding: replaces SinusoidalPositionEmbeddings.forward + UNetMini.time_mlp +
+ * the six Block.time_mlp heads (diffusion/model.py:18-30, 82-87, 56).
+ * temb_dev [nt,E] (may be NULL), heads_dev [nt,6,C] = SiLU(Linear_k(temb)). */
+int dm_time_embed(dm_unet* m, const float* packed_dev, const int64_t* t_dev, int nt,
+                  const float* cond_dev, float* temb_dev, float* heads_dev, void* stream);
+
+/* ---- sampler step: replaces DDPMScheduler.step (diffusion/schedulers.py:94-131) and
+ * DDIMSampler.step (diffusion/sampler.py:102-134).
+ * coef[5] = { sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev), sqrt(pv_t)*eta }.
+ * out = c2*((x - c0*eps)/c1) + c3*eps (+ c4*noise when noise_dev != NULL), evaluated in the
+ * reference's operation order without FMA contraction.  out_dev may alias x_dev. */
+int dm_sampler_step(const float* x_dev, const float* eps_dev, const float* noise_dev,
+                    const float* coef_host, float* out_dev, size_t count, void* stream);
+
+/* Per-step coefficient table from the schedule tables (host, fp32 arithmetic as torch):
+ * coefs_host[n][8] (5 used, 3 pad).  Tables are DDPMScheduler.alphas_cumprod,
+ * .alphas_cumprod_prev, .posterior_variance (diffusion/schedulers.py:41-54), length T. */
+int dm_sampler_coefs(const float* acp_host, const float* acp_prev_host, const float* pv_host,
+                     int T, const int64_t* timesteps_host, int n, float eta, float* coefs_host);
+
+/* ---- whole reverse-diffusion loop: replaces AncestralSampler.__call__ /
+ * DDIMSampler.__call__ (diffusion/sampler.py:45-76, 136-172).
+ * x_dev [B,Cin,H,W]: x_T on entry, final sample on exit (requires Cin == Cout).
+ * timesteps_dev int64[n] (ascending, as DDPMScheduler.set_timesteps produces),
+ * coefs_dev float[n][8] (dm_sampler_coefs, uploaded by the caller),
+ * noise_dev: NULL (eta == 0) or [n,B,Cin,H,W] host-drawn noise in loop order.
+ * cond_dev / guidance: build-defined classifier-free guidance (cond_dev NULL = off):
+ *   cond_dev [2B,E] = embeddings for [labels ; null label]; the denoiser runs on the doubled
+ *   batch and eps = eps_u + guidance*(eps_c - eps_u).
+ * use_graph != 0: the step loop is captured once into a hipGraph (chunks of <= 50 steps
+ * that read a device-side step counter) and replayed; 0: eager launches on `stream`. */
+int dm_sample(dm_unet* m, const float* packed_dev, float* x_dev, int B, int H, int W,
+              const int64_t* timesteps_dev, const float* coefs_dev, int n,
+              const float* noise_dev, const float* cond_dev, float guidance,
+              void* workspace_dev, size_t workspace_bytes, int use_graph, void* stream);
+
+/* ---- single operators (NHWC), exported for the per-kernel parity tests ------------------
+ * kind: 0 = Conv2d 3x3 pad 1 (model.py:42,45,47,99,102), 1 = Conv2d 4x4 stride 2 pad 1
+ * (model.py:46), 2 = ConvTranspose2d 4x4 stride 2 pad 1 (model.py:43). */
+size_t dm_conv_packed_floats(int kind, int cin, int cout);
+int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev,
+                        void* stream);
+/* y = conv(concat(f(x1), x2)) + bias.  f = identity when stats_in_dev == NULL, else
+ * f(x) = SiLU(GroupNorm8(x; gamma, beta)) + temb (Block.forward, model.py:54-62) with the
+ * group statistics given as `pin` partial (mean, M2) pairs per (image, group):
+ * stats_in_dev [B][pin][8][2], each over cnt_in elements.  temb_dev: NULL or [*,C1] with
+ * per-image stride temb_stride (0 = shared by the batch).  stats_out_dev: NULL or
+ * [B][pout][8][2] partial statistics of y (pout as dm_conv_stats_partials reports).
+ * H, W are the INPUT spatial dims. */
+int dm_conv_stats_partials(int kind, int H, int W);
+int dm_conv2d(int kind, const float* x1_dev, int c1, const float* x2_dev, int c2,
+              const float* packed_w_dev, const float* bias_dev, int cout,
+              const float* stats_in_dev, int pin, float cnt_in, const float* gamma_dev,
+              const float* beta_dev, const float* temb_dev, int temb_stride, float* y_dev,
+              float* stats_out_dev, int B, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DM_SAMPLER_H */

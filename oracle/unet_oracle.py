@@ -13,6 +13,7 @@ It is a build-owned restatement (stock torch-CPU ops, functional style over a pl
 * ``make_schedule``         <- diffusion/schedulers.py:30-63 (+ cosine :65-72)
 * ``make_timesteps``        <- diffusion/schedulers.py:140-147
 * ``sampler_step``          <- diffusion/schedulers.py:113-131 == diffusion/sampler.py:117-134
+  (``sampler_step_np``: the same in strict IEEE fp32 numpy)
 * ``sample``                <- diffusion/sampler.py:45-76 and :136-172
 
 Parity pinning: the reference holds no golden vectors of its own, so this
@@ -135,6 +136,26 @@ def sampler_step(sched: Dict[str, Tensor], eps: Tensor, t: Tensor, x: Tensor,
         std = torch.sqrt(sched["posterior_variance"][t].view(-1, 1, 1, 1)) * eta
         mean = mean + std * noise
     return mean
+
+
+def sampler_step_np(sched: Dict[str, Tensor], eps: Tensor, t: int, x: Tensor,
+                    eta: float = 0.0, noise: Optional[Tensor] = None) -> Tensor:
+    """The same update in strict IEEE-754 fp32 with numpy (one correctly rounded operation per
+    step, reference operation order).  ``torch.sqrt`` on CPU goes through MKL VML, whose last
+    bit differs between host CPU vendors (seen: Intel build host vs the AMD EPYC GPU-box host,
+    sqrt(1-a_1) one ulp apart), so bit-exactness of the HIP kernel is asserted against this
+    restatement and closeness (<= 1e-6 relative) against ``sampler_step``."""
+    import numpy as np
+    f = np.float32
+    a = sched["alphas_cumprod"][t].numpy().astype(f)
+    ap = sched["alphas_cumprod_prev"][t].numpy().astype(f)
+    c0, c1, c2, c3 = np.sqrt(f(1) - a), np.sqrt(a), np.sqrt(ap), np.sqrt(f(1) - ap)
+    xn, en = x.numpy(), eps.numpy()
+    out = c2 * ((xn - c0 * en) / c1) + c3 * en
+    if eta > 0:
+        c4 = np.sqrt(sched["posterior_variance"][t].numpy().astype(f)) * f(eta)
+        out = out + c4 * noise.numpy()
+    return torch.from_numpy(out.astype(f))
 
 
 @torch.no_grad()

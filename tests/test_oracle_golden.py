@@ -82,3 +82,14 @@ def test_class_conditioner(golden):
     cd = torch.load(os.path.join(os.path.dirname(__file__), "golden", "classcond11_seed43.pth"),
                     weights_only=True)
     assert mad(O.class_conditioner(cd, golden["cc_labels"]), golden["cc_out"]) <= TOL
+
+
+def test_strict_numpy_step_matches_torch_step():
+    sched = O.make_schedule()
+    torch.manual_seed(3)
+    x, e, nz = torch.randn(2, 1, 32, 32), torch.randn(2, 1, 32, 32), torch.randn(2, 1, 32, 32)
+    for t in (0, 1, 500, 999):
+        for eta in (0.0, 0.7):
+            a = O.sampler_step_np(sched, e, t, x, eta, nz)
+            b = O.sampler_step(sched, e, torch.tensor(t), x, eta, nz)
+            assert mad(a, b) <= 1e-6 * max(1.0, b.abs().max().item())
