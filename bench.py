@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py — sampled images/s of the MI355X-native DDIM-50 sampler (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+A "step" is ONE full DDIM-50 sampling pass (50 denoiser evaluations + 50 sampler updates) over
+one batch of B=1024 synthetic 32x32 images per GPU (BASELINE.json configs[1]); x_T and the
+weights are resident in HBM when the timed region starts.  N>1 is launched by the driver with
+torch.distributed.run, one rank per GPU: every rank samples its own B images (weak scaling,
+no data-path collective inside the loop) and the finished samples are all-gathered over
+RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+
+Extra legs on rank 0 at N=1 (outside the timed region):
+  roofline     — dm_unet_profile: hipEvent pairs around every kernel launch of the denoiser on
+                 the launch stream; the dominant kernel class is the 3x3 implicit-GEMM conv.
+  cpu_baseline — the CPU oracle (oracle/unet_oracle.py, kind "port") on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMAGE_STEP = 364_249_088  # SURVEY 8(d), equals torch.utils.flop_counter on model.py:120-151
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak
+K_NAMES = ["init_conv", "conv3x3_mfma_t128", "conv3x3_mfma_t64", "conv4x4s2_mfma", "convT4x4s2_mfma_t128",
+           "convT4x4s2_mfma_t64", "final_conv", "time_embed", "sampler_step"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="images per GPU per pass")
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import diffusion_model_amd as d
+    from diffusion_model_amd import _lib
+
+    B, n = args.batch, args.ddim_steps
+    d.set_seed(42)
+    model = d.UNetMini(image_size=32).eval()       # random-init weights of the reference architecture
+    sched = d.DDPMScheduler()
+    smp = d.DDIMSampler(sched, num_inference_steps=n, eta=0.0)
+    # synthetic x_T: the full [world*B] draw, each rank takes its row slice
+    g = torch.Generator().manual_seed(42)
+    x_T = torch.randn((world * B, 1, 32, 32), generator=g)[rank * B:(rank + 1) * B].to(dev)
+    gathered = torch.empty((world * B, 1, 32, 32), device=dev) if world > 1 else None
+
+    def one_pass():
+        out = smp.sample_from(model, x_T)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    assert torch.isfinite(out).all()
+    images = world * B * args.steps
+    value = images / dt
+    res = {
+        "metric": "sampled images/sec (DDIM-50, 32x32 MNIST UNet)", "value": value, "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"DDIM-{n} eta=0, UNetMini(32x32, C=64) random-init seed 42, batch {B} per GPU, "
+                               "x_T resident in HBM (BASELINE configs[1])",
+                   "images_per_gpu": B, "ddim_steps": n, "parallelism": f"dp{world} (batch-sharded, final all-gather)"},
+        "achieved_tflops_whole_path": value * n * FLOP_PER_IMAGE_STEP / 1e12,
+        "frac_fp32_mfma_peak_whole_path": value * n * FLOP_PER_IMAGE_STEP / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        L = _lib.lib()
+        ws = model.workspace(B, 32, 32)
+        packed = model.packed_weights()
+        t_dev = torch.tensor([500], device=dev)
+        coef = sched.step_coefs(torch.tensor([500]), 0.0)[0]
+        cbuf = (C.c_float * 5)(*[float(v) for v in coef[:5]])
+        counts, ms = (C.c_int * 9)(), (C.c_float * 9)()
+        fl, by = (C.c_double * 9)(), (C.c_double * 9)()
+        xs = x_T.clone()
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for reps in (2, 10):  # first call warms up
+            _lib.check(L.dm_unet_profile(model._native(), _lib.ptr(packed), _lib.ptr(xs), _lib.ptr(t_dev), cbuf, B, 32, 32,
+                                         _lib.ptr(ws), ws.numel(), reps, side.cuda_stream, counts, ms, fl, by))
+        per = {}
+        tot_ms = sum(ms[k] for k in range(9))
+        for k in range(9):
+            if counts[k]:
+                per[K_NAMES[k]] = {"launches": counts[k], "avg_us": 1e3 * ms[k] / counts[k], "share": ms[k] / tot_ms,
+                                   "tflops": fl[k] / (ms[k] * 1e-3) / 1e12, "alg_gbps": by[k] / (ms[k] * 1e-3) / 1e9}
+        k = 1  # dominant: conv_mfma_kernel<2,0,64>
+        ach = fl[k] / (ms[k] * 1e-3) / 1e12
+        res["roofline"] = {"kernel": "conv_mfma_kernel<2,0,64> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                           "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                           "avg_launch_us": 1e3 * ms[k] / counts[k], "flop_per_launch": fl[k] / counts[k],
+                           "share_of_denoiser_time": ms[k] / tot_ms}
+        res["kernels"] = per
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import unet_oracle as O
+        sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
+        cb = 128
+        xc = x_T[:cb].cpu()
+        O.sample(sd, O.make_schedule(), xc.shape, 2, 0.0, x_T=xc)  # warm-up
+        t0 = time.perf_counter()
+        ref = O.sample(sd, O.make_schedule(), xc.shape, n, 0.0, x_T=xc)
+        ct = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": cb / ct, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"CPU oracle (torch-CPU restatement of the reference sampler), DDIM-{n}, batch {cb}, "
+                                         f"{ct:.1f} s"}
+        err = (out[:cb].cpu() - ref).abs().max().item()
+        res["check_max_abs_vs_cpu_oracle"] = err
+
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,32 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+// ------------------------------------------------------------------ per-launch profiler
+// dm_unet_profile brackets every launch of one forward with hipEvents (on the launch stream)
+// and books its algorithmic FLOPs / bytes per kernel class; inactive otherwise.
+struct ProfRec { int cls; hipEvent_t a, b; };
+struct Prof {
+  std::vector<ProfRec> recs;
+  double flops[DM_K_COUNT] = {0};
+  double bytes[DM_K_COUNT] = {0};
+};
+thread_local Prof* g_prof = nullptr;
+
+struct ProfScope {
+  int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
+  ProfScope(int cls_, hipStream_t s_, double flops, double bytes) : cls(cls_), s(s_), on(g_prof != nullptr) {
+    if (!on) return;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+    g_prof->flops[cls] += flops; g_prof->bytes[cls] += bytes;
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(b, s);
+    g_prof->recs.push_back({cls, a, b});
+  }
+};
+
 // ------------------------------------------------------------------ conv geometry
 struct ConvGeo {
   int MT, th_log, tw_log, ni, tiles_x, tiles_per_img, hth, htw, Hb, Wb, pout, OH, OW;
@@ -91,6 +117,13 @@ int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
+  const int cls = KIND == 0 ? (MB == 2 ? DM_K_CONV3_128 : DM_K_CONV3_64)
+                            : KIND == 1 ? DM_K_DOWN : (MB == 2 ? DM_K_UP_128 : DM_K_UP_64);
+  const double opix = (double)a.B * a.Hb * a.Wb * (KIND == 2 ? 4 : 1);
+  const double ipix = (double)a.B * a.H * a.W;
+  const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : 4;
+  const int cin = a.C1 + a.C2;
+  ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 4.0 * (ipix * cin + opix * a.Cout + taps * (KIND == 2 ? 4 : 1) * cin * a.Cout));
   hipLaunchKernelGGL((conv_mfma_kernel<MB, KIND, KC>), grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -225,6 +258,7 @@ int launch_time_embed(const dm_unet* m, const float* P, const int64_t* t, int nt
   a.w1 = P + m->o_tm1w; a.b1 = P + m->o_tm1b; a.w2 = P + m->o_tm2w; a.b2 = P + m->o_tm2b;
   for (int k = 0; k < 6; ++k) { a.hw[k] = P + m->blk[k].tmw; a.hb[k] = P + m->blk[k].tmb; }
   a.t = t; a.cond = cond; a.temb = temb; a.heads = heads; a.E = m->E; a.C = m->C;
+  ProfScope ps(DM_K_TIME, s, 2.0 * nt * (2.0 * m->E * m->E + 6.0 * m->C * m->E), 4.0 * (2.0 * m->E * m->E + 6.0 * m->C * m->E));
   hipLaunchKernelGGL(time_embed_kernel, dim3((unsigned)nt), dim3(256), 3 * m->E * sizeof(float), s, a);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -243,6 +277,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     const size_t total = (size_t)B * H * W * (C / 4);
     unsigned blocks = (unsigned)((total + 255) / 256);
     if (blocks > 65536u * 4) blocks = 65536u * 4;
+    ProfScope ps(DM_K_INIT, s, 2.0 * B * H * W * C * 9 * m->Cin, 4.0 * B * H * W * (m->Cin + C));
     hipLaunchKernelGGL(init_conv_kernel, dim3(blocks), dim3(256), lds, s, x, P + m->o_initw, P + m->o_initb, w.A0, B, m->Cin, H, W, C);
     HIP_TRY(hipGetLastError());
   }
@@ -286,6 +321,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   {  // final_conv (model.py:111-115,151)
     const ConvGeo pg = conv_geo(2, H / 2, W / 2, C);
     const size_t lds = (size_t)(3 * C + m->Cout * C) * sizeof(float);
+    ProfScope ps(DM_K_FINAL, s, 2.0 * B * H * W * C * m->Cout, 4.0 * B * H * W * (C + m->Cout));
     hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)(B * (H * W / 64))), dim3(256), lds, s, w.A0, w.SA, pg.pout,
                        pg.cnt_out, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H * W, C, m->Cout);
     HIP_TRY(hipGetLastError());
@@ -305,6 +341,7 @@ int launch_step(const float* x, const float* eps, const float* noise, const floa
   size_t blocks = (count / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks == 0) blocks = 1;
+  ProfScope ps(DM_K_STEP, s, 6.0 * count, 4.0 * count * (noise ? 4 : 3));
   hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -528,6 +565,38 @@ int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, co
     if (get_graph(n % S0, &ex)) return 1;
     HIP_TRY(hipGraphLaunch(ex, s));
   }
+  return 0;
+}
+
+int dm_unet_profile(dm_unet* m, const float* packed, float* x, const int64_t* t_dev, const float* coef_host,
+                    int B, int H, int W, void* ws, size_t ws_bytes, int reps, void* stream,
+                    int* counts, float* ms, double* flops, double* bytes) {
+  if (!m || !packed || !x || !t_dev || !coef_host || !ws || !counts || !ms || !flops || !bytes)
+    return fail("dm_unet_profile: null argument");
+  if (check_geometry(m, B, H, W)) return 1;
+  if (m->Cin != m->Cout) return fail("dm_unet_profile needs in_channels == out_channels");
+  Workspace w = carve(m, ws, B, H, W, 1);
+  if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes", ws_bytes, w.bytes);
+  hipStream_t s = (hipStream_t)stream;
+  Prof prof;
+  g_prof = &prof;
+  int rc = 0;
+  for (int r = 0; r < reps && !rc; ++r) {
+    rc = launch_time_embed(m, packed, t_dev, 1, nullptr, w.temb, w.heads, s);
+    if (!rc) rc = unet_body(m, packed, x, w.eps, w.heads, 0, 0, nullptr, 0, w, B, H, W, s);
+    // out-of-place (into the workspace) so repeated profiling passes see the same input
+    if (!rc) rc = launch_step(x, w.eps, nullptr, nullptr, nullptr, 0, coef_host, w.xx, (size_t)B * m->Cin * H * W, 0, 0.f, s);
+  }
+  g_prof = nullptr;
+  hipError_t se = hipStreamSynchronize(s);
+  for (int k = 0; k < DM_K_COUNT; ++k) { counts[k] = 0; ms[k] = 0.f; flops[k] = prof.flops[k]; bytes[k] = prof.bytes[k]; }
+  for (auto& r : prof.recs) {
+    float t = 0.f;
+    if (se == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { counts[r.cls]++; ms[r.cls] += t; }
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  if (rc) return 1;
+  HIP_TRY(se);
   return 0;
 }
 

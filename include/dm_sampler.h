@@ -103,6 +103,27 @@ int dm_sample(dm_unet* m, const float* packed_dev, float* x_dev, int B, int H, i
               const float* noise_dev, const float* cond_dev, float guidance,
               void* workspace_dev, size_t workspace_bytes, int use_graph, void* stream);
 
+/* ---- measurement aid (no reference counterpart): runs `reps` denoiser evaluations + sampler
+ * updates with a hipEvent pair (recorded on `stream`) around every kernel launch and returns,
+ * per kernel class, the launch count, the summed device time (ms) and the summed ALGORITHMIC
+ * FLOPs and bytes of those launches.  Synchronises the stream.  bench.py's roofline leg. */
+enum {
+  DM_K_INIT = 0,      /* init_conv_kernel                                   (HBM-bound) */
+  DM_K_CONV3_128 = 1, /* conv_mfma_kernel<2,0,64>: 3x3 convs, 128-pixel tiles (MFMA)    */
+  DM_K_CONV3_64 = 2,  /* conv_mfma_kernel<1,0,64>: 3x3 convs, 64-pixel tiles  (MFMA)    */
+  DM_K_DOWN = 3,      /* conv_mfma_kernel<1,1,32>: 4x4 stride-2 convs         (MFMA)    */
+  DM_K_UP_128 = 4,    /* conv_mfma_kernel<2,2,64>: transposed 4x4 s2          (MFMA)    */
+  DM_K_UP_64 = 5,     /* conv_mfma_kernel<1,2,64>                              (MFMA)    */
+  DM_K_FINAL = 6,     /* final_conv_kernel                                  (HBM-bound) */
+  DM_K_TIME = 7,      /* time_embed_kernel                                              */
+  DM_K_STEP = 8,      /* sampler_step_kernel                                (HBM-bound) */
+  DM_K_COUNT = 9
+};
+int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int64_t* t_dev,
+                    const float* coef_host, int B, int H, int W, void* workspace_dev,
+                    size_t workspace_bytes, int reps, void* stream, int* counts, float* ms,
+                    double* flops, double* bytes);
+
 /* ---- single operators (NHWC), exported for the per-kernel parity tests ------------------
  * kind: 0 = Conv2d 3x3 pad 1 (model.py:42,45,47,99,102), 1 = Conv2d 4x4 stride 2 pad 1
  * (model.py:46), 2 = ConvTranspose2d 4x4 stride 2 pad 1 (model.py:43). */
