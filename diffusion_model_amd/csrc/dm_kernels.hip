@@ -67,7 +67,7 @@ struct ConvArgs {
 };
 
 template <int MB, int KIND, int KC>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   constexpr int MT = 64 * MB;
   constexpr int RS = KC + 4;  // LDS row stride (floats): 16-B skew between consecutive pixels
   constexpr int S = (KIND == 1) ? 2 : 1;
@@ -105,36 +105,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   float* s_temb = s_beta + (tf ? p.C1 : 0);
   float* tile = s_temb + (tf ? p.ni * p.C1 : 0);
 
-  if (tf) {
-    const int G = p.C1 / DM_GROUPS;
-    const int step = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
-    const float* te = p.temb ? p.temb + (size_t)step * p.temb_step_stride : nullptr;
-    for (int idx = tid; idx < p.ni * p.C1; idx += 256) {
-      const int i = idx / p.C1, c = idx - i * p.C1;
-      const int n = img0 + i;
-      float mean = 0.f, scale = 0.f, tv = 0.f;
-      if (n < p.B) {
-        const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c / G)) * 2;
-        float msum = 0.f;
-        for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
-        mean = msum / (float)p.pin;
-        float m2 = 0.f, dev = 0.f;
-        for (int q = 0; q < p.pin; ++q) {
-          const float d = st[q * DM_GROUPS * 2] - mean;
-          m2 += st[q * DM_GROUPS * 2 + 1];
-          dev += d * d;
-        }
-        const float var = (m2 + p.cnt_in * dev) / (p.cnt_in * (float)p.pin);
-        scale = rsqrtf(var + DM_GN_EPS) * p.gamma[c];
-        if (te) tv = te[(size_t)n * p.temb_stride + c];
-      }
-      s_mean[idx] = mean;
-      s_scale[idx] = scale;
-      s_temb[idx] = tv;
-    }
-    for (int c = tid; c < p.C1; c += 256) s_beta[c] = p.beta[c];
-  }
-
   // ---- per-lane A-fragment base offsets (floats) into the halo tile at tap (0,0)
   int abase[MB];
 #pragma unroll
@@ -156,68 +126,135 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
   const size_t jstride = (size_t)nb32 * 256;
   const size_t tapstride = (size_t)(Cin >> 3) * jstride;
   const int nchunks = Cin / KC;
+  constexpr int V = KC / 4;
+  constexpr int U = 6;  // global loads kept in flight per thread while staging
+  const int items = NP * V;
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    __syncthreads();  // tables ready (chunk 0) / previous chunk's LDS reads done
-    // ---- stage: global -> (transform) -> LDS
-    {
-      const int cg0 = chunk * KC;
-      const bool from2 = cg0 >= p.C1;
-      const float* src = from2 ? p.x2 : p.x1;
-      const int Cs = from2 ? p.C2 : p.C1;
-      const int coff = from2 ? cg0 - p.C1 : cg0;
-      constexpr int V = KC / 4;
-      const int items = NP * V;
-      for (int idx = tid; idx < items; idx += 256) {
+    const int cg0 = chunk * KC;
+    const bool from2 = cg0 >= p.C1;
+    const float* src = from2 ? p.x2 : p.x1;
+    const int Cs = from2 ? p.C2 : p.C1;
+    const int coff = from2 ? cg0 - p.C1 : cg0;
+    // B fragments of tap 0 go first: they are not needed until the K loop
+    const float* wbase = p.wp + ((size_t)par * NT) * tapstride + (size_t)chunk * NJ * jstride +
+                         (size_t)(blockIdx.y * 2 + wn) * 256 + lane * 4;
+    float4 bq[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bq[j] = *reinterpret_cast<const float4*>(wbase + j * jstride);
+
+    if (chunk > 0) __syncthreads();  // previous chunk's LDS reads are done
+    // ---- stage: global -> (transform) -> LDS, U loads in flight per thread (HBM latency
+    // is ~2 us under load; one load at a time would make this phase latency-bound)
+    for (int base = 0; base < items; base += 256 * U) {  // uniform trip count (barrier inside)
+      float4 v[U];
+      int lofs[U], img[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * 256 + tid;
         const int pix = idx / V, c4 = idx - pix * V;
         const int r = __umulhi((unsigned)pix, p.mg_htw);
         const int hx = pix - r * htw;
         const int i = __umulhi((unsigned)r, p.mg_hth);
         const int hy = r - i * hth;
         const int iy = hy0 + hy, ix = hx0 + hx, n = img0 + i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-          v = *reinterpret_cast<const float4*>(src + (((size_t)n * p.H + iy) * p.W + ix) * Cs + coff + c4 * 4);
-          if (tf) {
-            const int c = coff + c4 * 4;
-            const float4 mu = *reinterpret_cast<const float4*>(s_mean + i * p.C1 + c);
-            const float4 sc = *reinterpret_cast<const float4*>(s_scale + i * p.C1 + c);
-            const float4 be = *reinterpret_cast<const float4*>(s_beta + c);
-            const float4 te = *reinterpret_cast<const float4*>(s_temb + i * p.C1 + c);
-            v.x = dm_silu((v.x - mu.x) * sc.x + be.x) + te.x;
-            v.y = dm_silu((v.y - mu.y) * sc.y + be.y) + te.y;
-            v.z = dm_silu((v.z - mu.z) * sc.z + be.z) + te.z;
-            v.w = dm_silu((v.w - mu.w) * sc.w + be.w) + te.w;
-          }
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        lofs[u] = (idx < items) ? pix * RS + c4 * 4 : -1;
+        img[u] = -1;  // -1: zero padding / out of range -> stays exactly 0 (no transform)
+        if (idx < items && n < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+          v[u] = *reinterpret_cast<const float4*>(src + (((size_t)n * p.H + iy) * p.W + ix) * Cs + coff + c4 * 4);
+          img[u] = i * p.C1 + coff + c4 * 4;
         }
-        *reinterpret_cast<float4*>(tile + pix * RS + c4 * 4) = v;
+      }
+      if (tf && chunk == 0 && base == 0) {
+        // GroupNorm tables, computed while the first batch of tile loads is in flight
+        const int G = p.C1 / DM_GROUPS;
+        const int step = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
+        const float* te = p.temb ? p.temb + (size_t)step * p.temb_step_stride : nullptr;
+        for (int idx = tid; idx < p.ni * p.C1; idx += 256) {
+          const int i = idx / p.C1, c = idx - i * p.C1;
+          const int n = img0 + i;
+          float mean = 0.f, scale = 0.f, tv = 0.f;
+          if (n < p.B) {
+            const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c / G)) * 2;
+            float msum = 0.f;
+            for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
+            mean = msum / (float)p.pin;
+            float m2 = 0.f, dev = 0.f;
+            for (int q = 0; q < p.pin; ++q) {
+              const float d = st[q * DM_GROUPS * 2] - mean;
+              m2 += st[q * DM_GROUPS * 2 + 1];
+              dev += d * d;
+            }
+            const float var = (m2 + p.cnt_in * dev) / (p.cnt_in * (float)p.pin);
+            scale = rsqrtf(var + DM_GN_EPS) * p.gamma[c];
+            if (te) tv = te[(size_t)n * p.temb_stride + c];
+          }
+          s_mean[idx] = mean;
+          s_scale[idx] = scale;
+          s_temb[idx] = tv;
+        }
+        for (int c = tid; c < p.C1; c += 256) s_beta[c] = p.beta[c];
+        __syncthreads();  // uniform condition
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (lofs[u] >= 0) {
+          float4 w = v[u];
+          if (tf && img[u] >= 0) {
+            const int c = coff + ((lofs[u] % RS) & ~3);
+            const float4 mu = *reinterpret_cast<const float4*>(s_mean + img[u]);
+            const float4 sc = *reinterpret_cast<const float4*>(s_scale + img[u]);
+            const float4 be = *reinterpret_cast<const float4*>(s_beta + c);
+            const float4 te = *reinterpret_cast<const float4*>(s_temb + img[u]);
+            w.x = dm_silu((w.x - mu.x) * sc.x + be.x) + te.x;
+            w.y = dm_silu((w.y - mu.y) * sc.y + be.y) + te.y;
+            w.z = dm_silu((w.z - mu.z) * sc.z + be.z) + te.z;
+            w.w = dm_silu((w.w - mu.w) * sc.w + be.w) + te.w;
+          }
+          *reinterpret_cast<float4*>(tile + lofs[u]) = w;
+        }
       }
     }
     __syncthreads();
 
-    // ---- K loop over taps x KC channels; B fragments stream from L2 one tap ahead
-    const float* wbase = p.wp + ((size_t)par * NT) * tapstride + (size_t)chunk * NJ * jstride +
-                         (size_t)(blockIdx.y * 2 + wn) * 256 + lane * 4;
-    float4 bq[NJ];
+    // ---- K loop over taps x KC channels, software-pipelined by hand:
+    //   group j of a tap = { LDS read of the NEXT group's A fragments ; 4*MB MFMAs on the
+    //   current ones ; global load of the next tap's B fragment j (into the slot just used) }.
+    // sched_barrier(0) pins that order: left alone, hipcc sinks the B loads to the end of the
+    // tap and waits vmcnt(0) on them, and issues each A read right before its first use.
+    float4 a0[MB], a1[MB];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) bq[j] = *reinterpret_cast<const float4*>(wbase + j * jstride);
+    for (int mb = 0; mb < MB; ++mb) a0[mb] = *reinterpret_cast<const float4*>(tile + abase[mb]);
+    int ty = 0, tx = 0;
     for (int tap = 0; tap < NT; ++tap) {
-      const int ty = tap / NTY, tx = tap - ty * NTY;
       const int tapoff = (ty * htw + tx) * RS;
-      const float* wnext = wbase + (size_t)((tap + 1 < NT) ? tap + 1 : tap) * tapstride;
+      // next tap (clamped at the end: the extra prefetch re-reads valid data and is unused)
+      int ntx = tx + 1, nty = ty;
+      if (ntx == NTY) { ntx = 0; ++nty; }
+      const bool last = tap + 1 == NT;
+      const int ntapoff = last ? tapoff : (nty * htw + ntx) * RS;
+      const float* wnext = wbase + (size_t)(last ? tap : tap + 1) * tapstride;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
+        float4* acur = (j & 1) ? a1 : a0;
+        float4* anxt = (j & 1) ? a0 : a1;
+        const int noff = (j + 1 < NJ) ? tapoff + (j + 1) * 8 : ntapoff;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) anxt[mb] = *reinterpret_cast<const float4*>(tile + abase[mb] + noff);
+        __builtin_amdgcn_sched_barrier(0);
         const float4 b = bq[j];
-        bq[j] = *reinterpret_cast<const float4*>(wnext + j * jstride);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-          const float4 a = *reinterpret_cast<const float4*>(tile + abase[mb] + tapoff + j * 8);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[mb], 0, 0, 0);
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[mb].x, b.x, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[mb].y, b.y, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[mb].z, b.z, acc[mb], 0, 0, 0);
+          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[mb].w, b.w, acc[mb], 0, 0, 0);
         }
+        bq[j] = *reinterpret_cast<const float4*>(wnext + j * jstride);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      tx = ntx; ty = nty;
     }
   }
 
