@@ -155,7 +155,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   const int kc = (c.kind == 1) ? 32 : 64;
   const size_t np = (size_t)g.ni * g.hth * g.htw;
   size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0);
-  const size_t epi_f = (size_t)g.MT * 8 + 64;
+  const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
   if (lds_f < epi_f) lds_f = epi_f;
   const size_t lds = lds_f * sizeof(float);
   if (lds > 160 * 1024) return fail("conv: tile needs %zu B of LDS (> 160 KiB)", lds);

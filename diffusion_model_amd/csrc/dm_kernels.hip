@@ -116,18 +116,14 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
     abase[mb] = ((i * hth + y * S) * htw + x * S) * RS + 4 * h;
   }
 
-  f32x16 acc[MB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+  f32x16 acc[MB];  // zeroed after the first chunk is staged (keeps staging's register peak low)
 
   const int nb32 = p.Cout >> 5;
   const size_t jstride = (size_t)nb32 * 256;
   const size_t tapstride = (size_t)(Cin >> 3) * jstride;
   const int nchunks = Cin / KC;
   constexpr int V = KC / 4;
-  constexpr int U = 6;  // global loads kept in flight per thread while staging
+  constexpr int U = 12;  // global loads in flight per thread while staging (one batch covers a tile)
   const int items = NP * V;
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -136,19 +132,14 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
     const float* src = from2 ? p.x2 : p.x1;
     const int Cs = from2 ? p.C2 : p.C1;
     const int coff = from2 ? cg0 - p.C1 : cg0;
-    // B fragments of tap 0 go first: they are not needed until the K loop
     const float* wbase = p.wp + ((size_t)par * NT) * tapstride + (size_t)chunk * NJ * jstride +
                          (size_t)(blockIdx.y * 2 + wn) * 256 + lane * 4;
-    float4 bq[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) bq[j] = *reinterpret_cast<const float4*>(wbase + j * jstride);
-
     if (chunk > 0) __syncthreads();  // previous chunk's LDS reads are done
     // ---- stage: global -> (transform) -> LDS, U loads in flight per thread (HBM latency
     // is ~2 us under load; one load at a time would make this phase latency-bound)
     for (int base = 0; base < items; base += 256 * U) {  // uniform trip count (barrier inside)
       float4 v[U];
-      int lofs[U], img[U];
+      int meta[U];  // (LDS float offset) | (table offset + 1) << 16; table part 0 = no transform
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int idx = base + u * 256 + tid;
@@ -159,11 +150,11 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
         const int hy = r - i * hth;
         const int iy = hy0 + hy, ix = hx0 + hx, n = img0 + i;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        lofs[u] = (idx < items) ? pix * RS + c4 * 4 : -1;
-        img[u] = -1;  // -1: zero padding / out of range -> stays exactly 0 (no transform)
+        meta[u] = (idx < items) ? pix * RS + c4 * 4 : -1;
+        // zero padding / images past the batch stay exactly 0 (no transform)
         if (idx < items && n < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
           v[u] = *reinterpret_cast<const float4*>(src + (((size_t)n * p.H + iy) * p.W + ix) * Cs + coff + c4 * 4);
-          img[u] = i * p.C1 + coff + c4 * 4;
+          meta[u] |= (i * p.C1 + coff + c4 * 4 + 1) << 16;
         }
       }
       if (tf && chunk == 0 && base == 0) {
@@ -199,24 +190,34 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (lofs[u] >= 0) {
+        if (meta[u] >= 0) {
           float4 w = v[u];
-          if (tf && img[u] >= 0) {
-            const int c = coff + ((lofs[u] % RS) & ~3);
-            const float4 mu = *reinterpret_cast<const float4*>(s_mean + img[u]);
-            const float4 sc = *reinterpret_cast<const float4*>(s_scale + img[u]);
+          const int lofs = meta[u] & 0xffff, tofs = (meta[u] >> 16) - 1;
+          if (tf && tofs >= 0) {
+            const int c = coff + (lofs % RS);
+            const float4 mu = *reinterpret_cast<const float4*>(s_mean + tofs);
+            const float4 sc = *reinterpret_cast<const float4*>(s_scale + tofs);
             const float4 be = *reinterpret_cast<const float4*>(s_beta + c);
-            const float4 te = *reinterpret_cast<const float4*>(s_temb + img[u]);
+            const float4 te = *reinterpret_cast<const float4*>(s_temb + tofs);
             w.x = dm_silu((w.x - mu.x) * sc.x + be.x) + te.x;
             w.y = dm_silu((w.y - mu.y) * sc.y + be.y) + te.y;
             w.z = dm_silu((w.z - mu.z) * sc.z + be.z) + te.z;
             w.w = dm_silu((w.w - mu.w) * sc.w + be.w) + te.w;
           }
-          *reinterpret_cast<float4*>(tile + lofs[u]) = w;
+          *reinterpret_cast<float4*>(tile + lofs) = w;
         }
       }
     }
+    float4 bq[NJ];  // B fragments of tap 0: their L2 latency hides behind the barrier
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bq[j] = *reinterpret_cast<const float4*>(wbase + j * jstride);
     __syncthreads();
+    if (chunk == 0) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+    }
 
     // ---- K loop over taps x KC channels, software-pipelined by hand:
     //   group j of a tap = { LDS read of the NEXT group's A fragments ; 4*MB MFMAs on the
@@ -258,90 +259,115 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
     }
   }
 
-  // ---- epilogue: + bias, store NHWC, GroupNorm partial statistics
-  const int col = blockIdx.y * 64 + wn * 32 + (lane & 31);
-  const float bv = p.bias[col];
+  // ---- epilogue: + bias; GroupNorm partial statistics; NHWC store through LDS
+  const int lc = wn * 32 + (lane & 31);  // column inside this workgroup's 64 output channels
+  const float bv = p.bias[blockIdx.y * 64 + lc];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] += bv;
   const int OW = (KIND == 0) ? p.W : (KIND == 1) ? (p.W >> 1) : (p.W << 1);
   const int OH = (KIND == 0) ? p.H : (KIND == 1) ? (p.H >> 1) : (p.H << 1);
+  constexpr int ORS = 68;                 // output staging row stride (floats)
+  float* otile = smem;                    // [MT][ORS]
+  float* sred = smem + MT * ORS;          // [4 waves][NSW][4]
+  float* s_mu = sred + 64;                // [<= 64]
+
+  __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      acc[mb][r] += bv;
       const int m = wm * (32 * MB) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int x = x0 + (m & (tw - 1));
-      const int y = y0 + ((m >> p.tw_log) & (th - 1));
-      const int n = img0 + (m >> (p.tw_log + p.th_log));
-      if (n < p.B) {
-        const int oy = (KIND == 2) ? 2 * y + py : y;
-        const int ox = (KIND == 2) ? 2 * x + px : x;
-        p.y[(((size_t)n * OH + oy) * OW + ox) * p.Cout + col] = acc[mb][r];
-      }
+      otile[m * ORS + lc] = acc[mb][r];
     }
-  }
 
   if (p.stats_out) {
-    // Two-pass (mean, then M2 about the tile mean) over the accumulator registers; every
-    // reduction is in a fixed order -> results do not depend on B or on dispatch order.
-    __syncthreads();  // K loop's LDS reads are done; reuse LDS
-    constexpr int NSEG = MT / 16;          // 16-row segments; a segment never straddles images
-    float* red = smem;                     // [NSEG][2][64]
-    float* s_mu = smem + NSEG * 2 * 64;    // [ni][groups in this 64-col tile]
-    const int G = p.Cout / DM_GROUPS;      // channels per group (8..64), divides 64
-    const int gpt = 64 / G;                // groups per cout tile
-    const int rows_img = (p.ni > 1) ? (th * tw) : MT;  // tile rows belonging to one image
-    const int segs_img = rows_img / 16;
+    // Two passes over the accumulator registers (mean, then M2 about that mean), reduced with
+    // cross-lane shuffles and a few LDS words in a fixed order: the result depends neither on
+    // the batch size nor on dispatch order.  A 16-row segment never straddles two images.
+    constexpr int NSW = MB * 2;                          // 16-row segments per wave
+    const int G = p.Cout / DM_GROUPS;                    // channels per group: 8, 16, 32 or 64
+    const int GL = G < 32 ? G : 32;                      // lanes of one group inside a wave
+    const int gpt = 64 / G;                              // groups in this 64-channel tile
+    const int rows_img = (p.ni > 1) ? (th * tw) : MT;    // tile rows that belong to one image
+    const bool perseg = rows_img < 32 * MB;              // (then rows_img == 16: one image per segment)
     const int nimg_t = MT / rows_img;
-    const int lc = wn * 32 + (lane & 31);
+    const int gg = (lane & 31) / GL;
+    float val[NSW];
+    for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int sg = 0; sg < 2; ++sg) {
-        float s = 0.f;
+        for (int sg = 0; sg < 2; ++sg) {
+          float mu = 0.f;
+          if (pass == 1) {
+            const int i = perseg ? (wm * MB + mb) * 2 + sg : (wm * 32 * MB) / rows_img;
+            mu = s_mu[i * gpt + lc / G];
+          }
+          float sm = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) s += acc[mb][sg * 8 + r];
-        red[(((wm * MB + mb) * 2 + sg) * 2 + h) * 64 + lc] = s;
-      }
-    }
-    __syncthreads();
-    if (tid < nimg_t * gpt) {
-      const int i = tid / gpt, g = tid - i * gpt;
-      float s = 0.f;
-      for (int sg = 0; sg < segs_img; ++sg)
-        for (int hh = 0; hh < 2; ++hh)
-          for (int c = 0; c < G; ++c) s += red[((i * segs_img + sg) * 2 + hh) * 64 + g * G + c];
-      s_mu[tid] = s / (float)(rows_img * G);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-      for (int sg = 0; sg < 2; ++sg) {
-        const int seg = (wm * MB + mb) * 2 + sg;
-        const float mu = s_mu[(seg / segs_img) * gpt + lc / G];
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const float d = acc[mb][sg * 8 + r] - mu;
-          s += d * d;
+          for (int r = 0; r < 8; ++r) {
+            const float d = acc[mb][sg * 8 + r] - mu;
+            sm += (pass == 0) ? d : d * d;
+          }
+          val[mb * 2 + sg] = sm;
         }
-        red[(seg * 2 + h) * 64 + lc] = s;
+      if (!perseg) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSW; ++k) t += val[k];
+        val[0] = t;
       }
+#pragma unroll
+      for (int k = 0; k < NSW; ++k) {
+        if (k == 0 || perseg) {
+          float v = val[k];
+          v += __shfl_xor(v, 32, 64);
+          for (int o = 1; o < GL; o <<= 1) v += __shfl_xor(v, o, 64);
+          if (h == 0 && ((lane & 31) % GL) == 0) sred[(wave * NSW + k) * 4 + gg] = v;
+        }
+      }
+      __syncthreads();
+      if (tid < nimg_t * gpt) {
+        const int i = tid / gpt, g = tid - i * gpt;
+        float sm = 0.f;
+        // waves (wm) and slots (k) that cover image i; wn / gg that cover group g
+        const int wm0 = perseg ? i / NSW : (i * rows_img) / (32 * MB);
+        const int nwm = perseg ? 1 : (rows_img / (32 * MB));
+        const int k = perseg ? i % NSW : 0;
+        const int wn0 = (g * G) >> 5, nwn = (G == 64) ? 2 : 1, g2 = ((g * G) & 31) / GL;
+        for (int a = 0; a < nwm; ++a)
+          for (int b = 0; b < nwn; ++b) sm += sred[(((wm0 + a) * 2 + wn0 + b) * NSW + k) * 4 + g2];
+        if (pass == 0) {
+          s_mu[tid] = sm / (float)(rows_img * G);
+        } else {
+          const int n = img0 + i;
+          if (n < p.B) {
+            const int pidx = ((KIND == 2) ? par * p.tiles_per_img : 0) + tin;
+            float* so = p.stats_out + (((size_t)n * p.pout + pidx) * DM_GROUPS + blockIdx.y * gpt + g) * 2;
+            so[0] = s_mu[tid];
+            so[1] = sm;
+          }
+        }
+      }
+      __syncthreads();
     }
+  } else {
     __syncthreads();
-    if (tid < nimg_t * gpt) {
-      const int i = tid / gpt, g = tid - i * gpt;
-      const int n = img0 + i;
-      if (n < p.B) {
-        float s = 0.f;
-        for (int sg = 0; sg < segs_img; ++sg)
-          for (int hh = 0; hh < 2; ++hh)
-            for (int c = 0; c < G; ++c) s += red[((i * segs_img + sg) * 2 + hh) * 64 + g * G + c];
-        const int pidx = ((KIND == 2) ? par * p.tiles_per_img : 0) + tin;
-        float* so = p.stats_out + (((size_t)n * p.pout + pidx) * DM_GROUPS + blockIdx.y * gpt + g) * 2;
-        so[0] = s_mu[tid];
-        so[1] = s;
-      }
+  }
+
+  // coalesced NHWC store: one pixel's 64 channels are 256 contiguous bytes
+  for (int idx = tid; idx < MT * 16; idx += 256) {
+    const int m = idx >> 4, c4 = idx & 15;
+    const int x = x0 + (m & (tw - 1));
+    const int y = y0 + ((m >> p.tw_log) & (th - 1));
+    const int n = img0 + (m >> (p.tw_log + p.th_log));
+    if (n < p.B) {
+      const int oy = (KIND == 2) ? 2 * y + py : y;
+      const int ox = (KIND == 2) ? 2 * x + px : x;
+      const float4 v = *reinterpret_cast<const float4*>(otile + m * ORS + c4 * 4);
+      *reinterpret_cast<float4*>(p.y + (((size_t)n * OH + oy) * OW + ox) * p.Cout + blockIdx.y * 64 + c4 * 4) = v;
     }
   }
 }
