@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdm_sampler.so")
+LIB_PATH = os.environ.get("DM_SAMPLER_LIB", os.path.join(_HERE, "libdm_sampler.so"))
 
 _lib = None
 

@@ -96,6 +96,10 @@ ConvGeo conv_geo(int kind, int H, int W, int Cout) {
   return g;
 }
 
+#ifdef DM_STAMPS
+unsigned long long* g_stamps = nullptr;  // diagnostic build: set through dm_debug_set_stamps
+#endif
+
 struct ConvCall {
   int kind;
   const float* x1; int c1;
@@ -152,6 +156,9 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   a.mg_htw = (unsigned)((0x100000000ull + g.htw - 1) / g.htw);
   a.mg_hth = (unsigned)((0x100000000ull + g.hth - 1) / g.hth);
   a.pout = g.pout;
+#ifdef DM_STAMPS
+  a.stamps = g_stamps;
+#endif
   const int kc = (c.kind == 1) ? 32 : 64;
   const size_t np = (size_t)g.ni * g.hth * g.htw;
   size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0);
@@ -599,6 +606,10 @@ int dm_unet_profile(dm_unet* m, const float* packed, float* x, const int64_t* t_
   HIP_TRY(se);
   return 0;
 }
+
+#ifdef DM_STAMPS
+void dm_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
+#endif
 
 size_t dm_conv_packed_floats(int kind, int cin, int cout) { return conv_packed_floats(kind, cin, cout); }
 

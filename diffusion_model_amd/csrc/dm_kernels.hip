@@ -18,7 +18,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float dm_silu(float v) {
   // v * sigmoid(v); __expf is v_exp_f32 (rel. err ~1e-7 here), well inside the 1e-4 budget
-  return v / (1.0f + __expf(-v));
+  // v_exp_f32 + v_rcp_f32 (each ~1 ulp) instead of an IEEE division: the transform runs on
+  // every staged element, and the full-precision divide alone cost ~13% of the conv kernel
+  return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -64,7 +66,16 @@ struct ConvArgs {
   int hth, htw;           // halo tile dims (input pixels)
   unsigned mg_htw, mg_hth; // ceil(2^32/d) magic dividers
   int pout;               // output partials per image
+#ifdef DM_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: [grid][4] s_memtime stamps
+#endif
 };
+
+#ifdef DM_STAMPS
+#define DM_STAMP(k) do { if (p.stamps && threadIdx.x == 0) { size_t o_ = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; p.stamps[o_ + (k)] = __builtin_amdgcn_s_memtime(); if ((k) == 0 || (k) == 3) p.stamps[o_ + 4 + ((k) == 3)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define DM_STAMP(k) do {} while (0)
+#endif
 
 template <int MB, int KIND, int KC>
 __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
@@ -76,6 +87,12 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   constexpr int NJ = KC / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
+  DM_STAMP(0);
+  // Staging and epilogue run at raised wave priority, the K loop at 0: the SIMD arbitrates by
+  // priority, then age, so without this a workgroup that is staging (younger) only gets the
+  // issue slots the co-resident MFMA loops leave over and its 12 loads/thread crawl (measured:
+  // staging took 1.5x a whole K loop).  An MFMA loop needs few issue slots and does not suffer.
+  __builtin_amdgcn_s_setprio(2);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -134,7 +151,10 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
     const int coff = from2 ? cg0 - p.C1 : cg0;
     const float* wbase = p.wp + ((size_t)par * NT) * tapstride + (size_t)chunk * NJ * jstride +
                          (size_t)(blockIdx.y * 2 + wn) * 256 + lane * 4;
-    if (chunk > 0) __syncthreads();  // previous chunk's LDS reads are done
+    if (chunk > 0) {
+      __builtin_amdgcn_s_setprio(2);
+      __syncthreads();
+    }  // previous chunk's LDS reads are done
     // ---- stage: global -> (transform) -> LDS, U loads in flight per thread (HBM latency
     // is ~2 us under load; one load at a time would make this phase latency-bound)
     for (int base = 0; base < items; base += 256 * U) {  // uniform trip count (barrier inside)
@@ -149,13 +169,16 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
         const int i = __umulhi((unsigned)r, p.mg_hth);
         const int hy = r - i * hth;
         const int iy = hy0 + hy, ix = hx0 + hx, n = img0 + i;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         meta[u] = (idx < items) ? pix * RS + c4 * 4 : -1;
-        // zero padding / images past the batch stay exactly 0 (no transform)
-        if (idx < items && n < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-          v[u] = *reinterpret_cast<const float4*>(src + (((size_t)n * p.H + iy) * p.W + ix) * Cs + coff + c4 * 4);
-          meta[u] |= (i * p.C1 + coff + c4 * 4 + 1) << 16;
-        }
+        // The load is UNCONDITIONAL from a clamped (always valid) address and the padding is a
+        // select afterwards: a load under a runtime condition makes hipcc branch around it and
+        // wait vmcnt(0) each time, which serialises the 12 loads (~2 us apiece).
+        const bool inb = idx < items && n < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const int cn = min(n, p.B - 1), cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+        const int cc = (idx < items) ? c4 * 4 : 0;
+        v[u] = *reinterpret_cast<const float4*>(src + (((size_t)cn * p.H + cy) * p.W + cx) * Cs + coff + cc);
+        // zero padding / images past the batch stay exactly 0 and get no transform
+        if (inb) meta[u] |= (i * p.C1 + coff + c4 * 4 + 1) << 16;
       }
       if (tf && chunk == 0 && base == 0) {
         // GroupNorm tables, computed while the first batch of tile loads is in flight
@@ -193,6 +216,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
         if (meta[u] >= 0) {
           float4 w = v[u];
           const int lofs = meta[u] & 0xffff, tofs = (meta[u] >> 16) - 1;
+          if (tofs < 0) w = make_float4(0.f, 0.f, 0.f, 0.f);
           if (tf && tofs >= 0) {
             const int c = coff + (lofs % RS);
             const float4 mu = *reinterpret_cast<const float4*>(s_mean + tofs);
@@ -212,7 +236,9 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bq[j] = *reinterpret_cast<const float4*>(wbase + j * jstride);
     __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
     if (chunk == 0) {
+      DM_STAMP(1);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -259,6 +285,8 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
     }
   }
 
+  DM_STAMP(2);
+  __builtin_amdgcn_s_setprio(2);
   // ---- epilogue: + bias; GroupNorm partial statistics; NHWC store through LDS
   const int lc = wn * 32 + (lane & 31);  // column inside this workgroup's 64 output channels
   const float bv = p.bias[blockIdx.y * 64 + lc];
@@ -370,6 +398,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
       *reinterpret_cast<float4*>(p.y + (((size_t)n * OH + oy) * OW + ox) * p.Cout + blockIdx.y * 64 + c4 * 4) = v;
     }
   }
+  DM_STAMP(3);
 }
 
 // Pack a conv weight into MFMA B-fragment order (see conv_mfma_kernel).
