@@ -66,15 +66,15 @@ def main():
     sched = d.DDPMScheduler()
     smp = d.DDIMSampler(sched, num_inference_steps=n, eta=0.0)
     # synthetic x_T: the full [world*B] draw, each rank takes its row slice
+    from diffusion_model_amd.distributed import sample_sharded, sampler_fn
     g = torch.Generator().manual_seed(42)
-    x_T = torch.randn((world * B, 1, 32, 32), generator=g)[rank * B:(rank + 1) * B].to(dev)
-    gathered = torch.empty((world * B, 1, 32, 32), device=dev) if world > 1 else None
+    x_T_full = torch.randn((world * B, 1, 32, 32), generator=g).to(dev)  # same draw on every rank
+    x_T = x_T_full[rank * B:(rank + 1) * B]
+    fn = sampler_fn(smp, model)
 
     def one_pass():
-        out = smp.sample_from(model, x_T)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
-        return out
+        # rank r samples rows [r*B, (r+1)*B); one RCCL all-gather of the finished samples
+        return sample_sharded(fn, x_T_full)
 
     def barrier():
         if world > 1:
@@ -93,7 +93,8 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
-    assert torch.isfinite(out).all()
+    assert torch.isfinite(out).all() and out.shape[0] == world * B
+    out = out[rank * B:(rank + 1) * B]
     images = world * B * args.steps
     value = images / dt
     res = {
