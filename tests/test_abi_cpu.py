@@ -1,0 +1,85 @@
+"""No-GPU checks: the C-ABI library loads and exports every symbol include/dm_sampler.h
+declares; host-only entry points (coefficient table, geometry queries, argument checks) behave;
+the drop-in classes keep the reference's surface and refuse to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import diffusion_model_amd as d
+from diffusion_model_amd import _lib
+from oracle import unet_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dm_sampler.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in dm_sampler.h but not exported"
+        assert n in _lib.EXPORTS, f"{n} has no ctypes signature in _lib.py"
+    assert L.dm_version() >= 1
+
+
+def test_sampler_coefs_host_table_matches_torch():
+    s = d.DDPMScheduler()
+    o = O.make_schedule()
+    ts = torch.tensor([0, 1, 20, 500, 980, 999])
+    c = s.step_coefs(ts, 0.7)
+    a, ap, pv = o["alphas_cumprod"][ts], o["alphas_cumprod_prev"][ts], o["posterior_variance"][ts]
+    ref = torch.stack([torch.sqrt(1 - a), torch.sqrt(a), torch.sqrt(ap), torch.sqrt(1 - ap), torch.sqrt(pv) * 0.7], 1)
+    assert (c[:, :5] - ref).abs().max().item() <= 1e-7  # MKL sqrt may differ in the last bit by host
+    with pytest.raises(RuntimeError, match="out of range"):
+        s.step_coefs(torch.tensor([1000]), 0.0)
+
+
+def test_scheduler_surface_and_tables(golden):
+    s = d.DDPMScheduler()
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "posterior_variance"):
+        assert torch.equal(getattr(s, k).cpu(), golden[f"sched_linear_{k}"])
+    c = d.DDPMScheduler(beta_schedule="cosine")
+    assert torch.equal(c.betas.cpu(), golden["sched_cosine_betas"])
+    assert len(s) == 1000 and s.scale_model_input(torch.ones(1)) is not None
+    s.set_timesteps(50)
+    assert torch.equal(s.timesteps.cpu(), golden["timesteps_50"])
+    s.set_timesteps(30)
+    assert torch.equal(s.timesteps.cpu(), golden["timesteps_30"])
+    # samplers mutate the caller's scheduler (sampler.py:26,100)
+    d.DDIMSampler(s, num_inference_steps=10)
+    assert s.timesteps.numel() == 10
+    with pytest.raises(ValueError):
+        d.create_sampler("deterministic", s)
+
+
+def test_geometry_queries_and_argument_errors():
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.dm_unet_create(C.byref(h), 1, 1, 48, 128) != 0 and b"model_channels" in L.dm_last_error()
+    _lib.check(L.dm_unet_create(C.byref(h), 1, 1, 64, 128))
+    assert L.dm_unet_packed_floats(h) > 1_106_241  # packed blob holds every parameter (+ padding)
+    w1, w2 = L.dm_unet_workspace_bytes(h, 8, 32, 32, 1), L.dm_unet_workspace_bytes(h, 16, 32, 32, 1)
+    assert 0 < w1 < w2
+    assert L.dm_conv_stats_partials(0, 32, 32) == 8 and L.dm_conv_stats_partials(2, 16, 16) == 8
+    assert L.dm_conv_stats_partials(0, 4, 4) == 1
+    assert L.dm_conv_packed_floats(0, 64, 64) == 9 * 64 * 64 and L.dm_conv_packed_floats(2, 64, 64) == 16 * 64 * 64
+    assert L.dm_unet_forward(h, None, None, None, 1, None, None, 1, 32, 32, None, 0, None) != 0
+    L.dm_unet_destroy(h)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_no_cpu_fallback():
+    m = d.UNetMini(image_size=32)
+    with pytest.raises(RuntimeError, match="GPU"):
+        m(torch.zeros(1, 1, 32, 32), torch.tensor(0))
+    with pytest.raises(RuntimeError, match="GPU"):
+        d.DDPMScheduler().step(torch.zeros(1, 1, 32, 32), 0, torch.zeros(1, 1, 32, 32))
