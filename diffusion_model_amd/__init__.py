@@ -3,8 +3,9 @@ diffusion.model / diffusion.schedulers / diffusion.sampler classes."""
 from .model import UNetMini, Block, SinusoidalPositionEmbeddings
 from .schedulers import DDPMScheduler, DDIMScheduler
 from .sampler import AncestralSampler, DDIMSampler, create_sampler
+from .conditioning import ClassConditioner, create_conditioner
 from .utils import get_device, set_seed, count_parameters
 
 __all__ = ["UNetMini", "Block", "SinusoidalPositionEmbeddings", "DDPMScheduler", "DDIMScheduler",
-           "AncestralSampler", "DDIMSampler", "create_sampler", "get_device", "set_seed",
+           "ClassConditioner", "create_conditioner", "AncestralSampler", "DDIMSampler", "create_sampler", "get_device", "set_seed",
            "count_parameters"]

@@ -259,8 +259,10 @@ int check_geometry(const dm_unet* m, int B, int H, int W) {
 }
 
 int launch_time_embed(const dm_unet* m, const float* P, const int64_t* t, int nt, const float* cond,
-                      float* temb, float* heads, hipStream_t s) {
+                      float* temb, float* heads, hipStream_t s, const int* step_ptr = nullptr, int step_off = 0,
+                      int t_stride = 1) {
   TimeArgs a;
+  a.step_ptr = step_ptr; a.step_off = step_off; a.t_stride = t_stride;
   a.freqs = P + m->o_freqs;
   a.w1 = P + m->o_tm1w; a.b1 = P + m->o_tm1b; a.w2 = P + m->o_tm2w; a.b2 = P + m->o_tm2b;
   for (int k = 0; k < 6; ++k) { a.hw[k] = P + m->blk[k].tmw; a.hb[k] = P + m->blk[k].tmb; }
@@ -515,14 +517,24 @@ int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, co
   if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes", ws_bytes, w.bytes);
   hipStream_t s = (hipStream_t)stream;
   const size_t count = (size_t)B * m->Cin * H * W;
-  if (cfg) return fail("dm_sample: classifier-free guidance is not implemented yet");
-  // Time embeddings of all n steps up front: they depend on t only.
-  if (launch_time_embed(m, packed, ts_dev, n, nullptr, nullptr, w.heads, s)) return 1;
+  // Time embeddings of all n steps up front: they depend on t only.  With
+  // guidance every image has its own embedding (time + class): computed per step for 2B rows.
+  if (!cfg && launch_time_embed(m, packed, ts_dev, n, nullptr, nullptr, w.heads, s)) return 1;
   const int hstep = 6 * m->C;
 
   auto one_step = [&](const int* step_ptr, int step_off) -> int {
-    if (unet_body(m, packed, x, w.eps, w.heads, 0, hstep, step_ptr, step_off, w, Bd, H, W, s)) return 1;
-    return launch_step(x, w.eps, noise_dev, coefs_dev, step_ptr, step_off, nullptr, x, count, 0, guidance, s);
+    if (!cfg) {
+      if (unet_body(m, packed, x, w.eps, w.heads, 0, hstep, step_ptr, step_off, w, Bd, H, W, s)) return 1;
+      return launch_step(x, w.eps, noise_dev, coefs_dev, step_ptr, step_off, nullptr, x, count, 0, 0.f, s);
+    }
+    // doubled batch [x;x] with embeddings [cond ; null] (build-defined CFG)
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, w.xx, count);
+    HIP_TRY(hipGetLastError());
+    if (launch_time_embed(m, packed, ts_dev, Bd, cond_dev, nullptr, w.heads, s, step_ptr, step_off, 0)) return 1;
+    if (unet_body(m, packed, w.xx, w.eps, w.heads, hstep, 0, nullptr, 0, w, Bd, H, W, s)) return 1;
+    return launch_step(x, w.eps, noise_dev, coefs_dev, step_ptr, step_off, nullptr, x, count, 1, guidance, s);
   };
 
   if (!use_graph) {
@@ -604,6 +616,16 @@ int dm_unet_profile(dm_unet* m, const float* packed, float* x, const int64_t* t_
   }
   if (rc) return 1;
   HIP_TRY(se);
+  return 0;
+}
+
+int dm_class_embed(const float* table_dev, int num_rows, int E, const float* w1, const float* b1, const float* w2,
+                   const float* b2, const int64_t* labels_dev, int n, float* out_dev, void* stream) {
+  if (!table_dev || !w1 || !b1 || !w2 || !b2 || !labels_dev || !out_dev) return fail("dm_class_embed: null argument");
+  if (n <= 0 || E <= 0 || E > 4096 || num_rows <= 0) return fail("dm_class_embed: bad sizes");
+  hipLaunchKernelGGL(class_embed_kernel, dim3((unsigned)n), dim3(256), 2 * E * sizeof(float), (hipStream_t)stream,
+                     table_dev, w1, b1, w2, b2, labels_dev, num_rows, E, out_dev);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 

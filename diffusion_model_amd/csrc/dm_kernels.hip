@@ -549,7 +549,9 @@ struct TimeArgs {
   const float *w1, *b1, *w2, *b2;  // [E,E],[E]
   const float* hw[6];            // [C,E]
   const float* hb[6];            // [C]
-  const int64_t* t;              // [nt]
+  const int64_t* t;              // timestep of entry n: t[tbase + n * t_stride]
+  const int* step_ptr;           // null or device step counter; tbase = *step_ptr + step_off
+  int step_off, t_stride;
   const float* cond;             // null or [nt,E]
   float* temb;                   // null or [nt,E]
   float* heads;                  // [nt,6,C]
@@ -563,7 +565,8 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const TimeArgs a) {
   float* te = hbuf + a.E; // [E]
   const int n = blockIdx.x;
   const int half = a.E >> 1;
-  const float tv = (float)a.t[n];
+  const int tbase = (a.step_ptr ? *a.step_ptr : 0) + a.step_off;
+  const float tv = (float)a.t[tbase + (size_t)n * a.t_stride];
   for (int i = threadIdx.x; i < half; i += 256) {
     const float arg = tv * a.freqs[i];
     e[i] = sinf(arg);
@@ -650,6 +653,37 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
       o.x = o.x + c4 * z.x; o.y = o.y + c4 * z.y; o.z = o.z + c4 * z.z; o.w = o.w + c4 * z.w;
     }
     reinterpret_cast<float4*>(a.out)[i] = o;
+  }
+}
+
+// ClassConditioner.forward (diffusion/conditioning.py:39-55): Embedding gather -> Linear ->
+// SiLU -> Linear.  One block per label.
+__global__ __launch_bounds__(256) void class_embed_kernel(const float* __restrict__ table, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, const int64_t* __restrict__ labels,
+                                                          int num_rows, int E, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* e = smem;
+  float* hbuf = smem + E;
+  const int n = blockIdx.x;
+  long long lab = labels[n];
+  if (lab < 0) lab = 0;
+  if (lab >= num_rows) lab = num_rows - 1;  // host validates; clamp keeps the access in bounds
+  for (int i = threadIdx.x; i < E; i += 256) e[i] = table[(size_t)lab * E + i];
+  __syncthreads();
+  for (int o = threadIdx.x; o < E; o += 256) {
+    const float* wr = w1 + (size_t)o * E;
+    float s = 0.f;
+    for (int i = 0; i < E; ++i) s += wr[i] * e[i];
+    s += b1[o];
+    hbuf[o] = s / (1.0f + expf(-s));
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < E; o += 256) {
+    const float* wr = w2 + (size_t)o * E;
+    float s = 0.f;
+    for (int i = 0; i < E; ++i) s += wr[i] * hbuf[i];
+    out[(size_t)n * E + o] = s + b2[o];
   }
 }
 

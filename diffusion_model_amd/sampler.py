@@ -33,14 +33,27 @@ class _SamplerBase:
         noises = torch.randn((n,) + tuple(shape)) if self.eta > 0 else None
         return x_T, noises
 
-    def sample_from(self, model, x_T, noises=None, progress_bar=False):
-        """Run the loop from given x_T (and per-step noises [n,*shape] when eta > 0)."""
+    def sample_from(self, model, x_T, noises=None, progress_bar=False, cond_emb=None, null_emb=None,
+                    guidance_scale=1.0):
+        """Run the loop from given x_T (and per-step noises [n,*shape] when eta > 0).
+
+        Build-defined classifier-free guidance (UNetMini only): ``cond_emb`` [B,E] and
+        ``null_emb`` [B,E] or [1,E] are added to the time embedding of the conditional /
+        unconditional halves of a doubled batch; eps = eps_u + guidance_scale*(eps_c - eps_u)."""
         timesteps = self.scheduler.timesteps
         n = timesteps.numel()
         if self.eta > 0 and noises is None:
             raise RuntimeError("eta > 0 needs per-step noise")
         if isinstance(model, UNetMini):
-            return self._fused(model, x_T, noises if self.eta > 0 else None, timesteps)
+            cond = None
+            if cond_emb is not None:
+                B = x_T.shape[0]
+                if null_emb is None:
+                    raise RuntimeError("guidance needs null_emb (embedding of the null class)")
+                cond = torch.cat([cond_emb.reshape(B, -1), null_emb.reshape(-1, cond_emb.shape[-1]).expand(B, -1)])
+            return self._fused(model, x_T, noises if self.eta > 0 else None, timesteps, cond, guidance_scale)
+        if cond_emb is not None:
+            raise RuntimeError("guidance is implemented for this package's UNetMini only")
         x = x_T.to(self.device)
         it = tqdm.tqdm(timesteps, desc=self._desc) if progress_bar else timesteps
         for i, t in enumerate(it):
@@ -50,7 +63,7 @@ class _SamplerBase:
             x = self.scheduler.step(eps, t, x, eta=self.eta, noise=nz)
         return x
 
-    def _fused(self, model, x_T, noises, timesteps):
+    def _fused(self, model, x_T, noises, timesteps, cond=None, guidance=1.0):
         dev = model.packed_weights().device
         B, Cin, H, W = x_T.shape
         n = timesteps.numel()
@@ -58,7 +71,11 @@ class _SamplerBase:
         ts_dev = timesteps.to(dev, torch.int64).contiguous()
         coefs = self.scheduler.step_coefs(timesteps, self.eta).to(dev)
         nz = None if noises is None else noises.to(dev, torch.float32).contiguous()
-        ws = model.workspace(B, H, W, n)
+        if cond is not None:
+            cond = cond.to(dev, torch.float32).contiguous()
+            if cond.shape != (2 * B, model.time_emb_dim):
+                raise RuntimeError(f"cond must be [{2 * B},{model.time_emb_dim}]")
+        ws = model.workspace(B if cond is None else 2 * B, H, W, n)
         packed = model.packed_weights()
         cur = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
@@ -66,9 +83,9 @@ class _SamplerBase:
         with torch.cuda.stream(side):
             _lib.check(_lib.lib().dm_sample(
                 model._native(), _lib.ptr(packed), _lib.ptr(x), B, H, W, _lib.ptr(ts_dev), _lib.ptr(coefs), n,
-                _lib.ptr(nz), None, 0.0, _lib.ptr(ws), ws.numel(), 1 if self.use_graph else 0, side.cuda_stream))
+                _lib.ptr(nz), _lib.ptr(cond), float(guidance), _lib.ptr(ws), ws.numel(), 1 if self.use_graph else 0, side.cuda_stream))
         cur.wait_stream(side)
-        for t_ in (x, ts_dev, coefs, nz, ws, packed):
+        for t_ in (x, ts_dev, coefs, nz, ws, packed, cond):
             if t_ is not None:
                 t_.record_stream(side)
         return x

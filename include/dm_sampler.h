@@ -103,6 +103,13 @@ int dm_sample(dm_unet* m, const float* packed_dev, float* x_dev, int B, int H, i
               const float* noise_dev, const float* cond_dev, float guidance,
               void* workspace_dev, size_t workspace_bytes, int use_graph, void* stream);
 
+/* ---- class embedding: replaces ClassConditioner.forward (diffusion/conditioning.py:39-55):
+ * out[n] = Linear2(SiLU(Linear1(table[labels[n]]))).  table [num_rows,E]; w1,w2 [E,E]; b1,b2 [E];
+ * labels int64[n] in [0,num_rows); out [n,E].  Feeds dm_unet_forward / dm_sample's cond_dev. */
+int dm_class_embed(const float* table_dev, int num_rows, int E, const float* w1_dev,
+                   const float* b1_dev, const float* w2_dev, const float* b2_dev,
+                   const int64_t* labels_dev, int n, float* out_dev, void* stream);
+
 /* ---- measurement aid (no reference counterpart): runs `reps` denoiser evaluations + sampler
  * updates with a hipEvent pair (recorded on `stream`) around every kernel launch and returns,
  * per kernel class, the launch count, the summed device time (ms) and the summed ALGORITHMIC

@@ -194,6 +194,18 @@ def cfg_eps(sd, cd, x: Tensor, t: Tensor, labels: Tensor, null_label: int, w: fl
     return eu + w * (ec - eu)
 
 
+@torch.no_grad()
+def cfg_sample(sd, cd, sched, x_T: Tensor, labels: Tensor, null_label: int, w: float,
+               num_inference_steps: int) -> Tensor:
+    """Build-defined guided DDIM loop (eta = 0) used as the oracle of dm_sample's CFG mode."""
+    T = sched["betas"].numel()
+    x = x_T.clone()
+    for t in make_timesteps(T, num_inference_steps):
+        e = cfg_eps(sd, cd, x, t, labels, null_label, w)
+        x = sampler_step(sched, e, t, x, 0.0)
+    return x
+
+
 def psnr(a: Tensor, b: Tensor, max_val: float) -> Tensor:
     """diffusion/eval.py:282-283, per image: 20 log10(max_val / sqrt(mse))."""
     mse = ((a - b) ** 2).flatten(1).mean(1)

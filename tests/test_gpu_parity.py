@@ -139,3 +139,50 @@ def test_create_sampler_errors():
         d.create_sampler("deterministic", d.DDPMScheduler())
     with pytest.raises(ValueError, match="Unknown beta schedule"):
         d.DDPMScheduler(beta_schedule="nope")
+
+
+# ---------------------------------------------------------------- build-defined extensions
+def _conditioner():
+    import os
+    cd = torch.load(os.path.join(os.path.dirname(__file__), "golden", "classcond11_seed43.pth"), weights_only=True)
+    cc = d.ClassConditioner(11, 128)
+    cc.load_state_dict(cd)
+    return cc, cd
+
+
+def test_class_conditioner_matches_reference(golden):
+    """ClassConditioner.forward (conditioning.py:39-55) vs the reference's own output."""
+    cc, _ = _conditioner()
+    out = cc(golden["cc_labels"]).cpu()
+    assert (out - golden["cc_out"]).abs().max().item() <= 2e-6
+    with pytest.raises(IndexError):
+        cc(torch.tensor([11]))
+
+
+def test_forward_with_class_embedding(golden, model, sd):
+    """Conditioning hook (build-defined, parity unpinned by the reference): oracle = CPU restatement."""
+    cc, cd = _conditioner()
+    x = golden["fwd_x"]
+    lab = torch.tensor([1, 5, 10, 0])
+    eps = model(x.to(DEV), torch.tensor(500), cond_emb=cc(lab)).cpu()
+    with torch.no_grad():
+        ref = O.unet_forward(sd, x, torch.tensor(500), cond_emb=O.class_conditioner(cd, lab))
+    assert (eps - ref).abs().max().item() <= EPS_TOL
+
+
+def test_cfg_ddim_sampling(golden, model, sd):
+    """Classifier-free guidance on the doubled batch (build-defined; oracle = CPU restatement)."""
+    cc, cd = _conditioner()
+    B, n, w = 3, 10, 3.0
+    torch.manual_seed(21)
+    x_T = torch.randn(B, 1, 32, 32)
+    lab = torch.tensor([2, 7, 9])
+    sched = d.DDPMScheduler()
+    smp = d.DDIMSampler(sched, num_inference_steps=n, eta=0.0)
+    cond, null = cc(lab), cc(torch.tensor([10]))
+    ref = O.cfg_sample(sd, cd, O.make_schedule(), x_T, lab, 10, w, n)
+    for use_graph in (False, True):
+        smp.use_graph = use_graph
+        out = smp.sample_from(model, x_T, cond_emb=cond, null_emb=null, guidance_scale=w).cpu()
+        assert O.psnr(out, ref, float(ref.max() - ref.min())).min().item() >= 40.0
+        assert (out - ref).abs().max().item() <= 1e-3
