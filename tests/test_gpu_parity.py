@@ -186,3 +186,23 @@ def test_cfg_ddim_sampling(golden, model, sd):
         out = smp.sample_from(model, x_T, cond_emb=cond, null_emb=null, guidance_scale=w).cpu()
         assert O.psnr(out, ref, float(ref.max() - ref.min())).min().item() >= 40.0
         assert (out - ref).abs().max().item() <= 1e-3
+
+
+def test_wide_unet_64x64x3_c256_matches_reference():
+    """BASELINE configs[4] geometry without the (build-defined) attention block: the reference's
+    own UNetMini(64, 3, 3, 256) output (oracle/gen_golden_wide.py).  Weights are the seeded
+    constructor init, reproduced here and guarded by two checksums."""
+    import os
+    G = torch.load(os.path.join(os.path.dirname(__file__), "golden", "golden_unet64_wide.pt"), weights_only=True)
+    d.set_seed(7)
+    m = d.UNetMini(image_size=64, in_channels=3, out_channels=3, model_channels=256).eval()
+    assert sum(p.numel() for p in m.parameters()) == int(G["nparams"])
+    assert abs(m.up3.conv1.weight.double().sum().item() - G["chk_up3_conv1"].item()) < 1e-9
+    assert abs(m.final_conv[2].weight.double().sum().item() - G["chk_final"].item()) < 1e-9
+    x = G["x"].to(DEV)
+    eps = m(x, torch.tensor(250)).cpu()
+    assert (eps - G["eps_t250"]).abs().max().item() <= EPS_TOL
+    eps = m(x, G["tb"].to(DEV)).cpu()
+    assert (eps - G["eps_tb"]).abs().max().item() <= EPS_TOL
+    # batch independence holds for the wide geometry too
+    assert torch.equal(m(x[1:2].contiguous(), torch.tensor(250)).cpu(), m(x, torch.tensor(250)).cpu()[1:2])
