@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 FLOP_PER_IMAGE_STEP = 364_249_088  # SURVEY 8(d), equals torch.utils.flop_counter on model.py:120-151
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak
 K_NAMES = ["init_conv", "conv3x3_mfma_t128", "conv3x3_mfma_t64", "conv4x4s2_mfma", "convT4x4s2_mfma_t128",
-           "convT4x4s2_mfma_t64", "final_conv", "time_embed", "sampler_step"]
+           "convT4x4s2_mfma_t64", "final_conv", "time_embed", "sampler_step", "attention"]
+NK = len(K_NAMES)  # DM_K_COUNT
 
 
 def main():
@@ -115,8 +116,8 @@ def main():
         t_dev = torch.tensor([500], device=dev)
         coef = sched.step_coefs(torch.tensor([500]), 0.0)[0]
         cbuf = (C.c_float * 5)(*[float(v) for v in coef[:5]])
-        counts, ms = (C.c_int * 9)(), (C.c_float * 9)()
-        fl, by = (C.c_double * 9)(), (C.c_double * 9)()
+        counts, ms = (C.c_int * NK)(), (C.c_float * NK)()
+        fl, by = (C.c_double * NK)(), (C.c_double * NK)()
         xs = x_T.clone()
         side = torch.cuda.Stream()
         torch.cuda.synchronize()
@@ -124,8 +125,8 @@ def main():
             _lib.check(L.dm_unet_profile(model._native(), _lib.ptr(packed), _lib.ptr(xs), _lib.ptr(t_dev), cbuf, B, 32, 32,
                                          _lib.ptr(ws), ws.numel(), reps, side.cuda_stream, counts, ms, fl, by))
         per = {}
-        tot_ms = sum(ms[k] for k in range(9))
-        for k in range(9):
+        tot_ms = sum(ms[k] for k in range(NK))
+        for k in range(NK):
             if counts[k]:
                 per[K_NAMES[k]] = {"launches": counts[k], "avg_us": 1e3 * ms[k] / counts[k], "share": ms[k] / tot_ms,
                                    "tflops": fl[k] / (ms[k] * 1e-3) / 1e12, "alg_gbps": by[k] / (ms[k] * 1e-3) / 1e9}

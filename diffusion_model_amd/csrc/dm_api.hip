@@ -76,8 +76,8 @@ ConvGeo conv_geo(int kind, int H, int W, int Cout) {
   ConvGeo g;
   g.Hb = (kind == 1) ? H / 2 : H;
   g.Wb = (kind == 1) ? W / 2 : W;
-  g.OH = (kind == 0) ? H : (kind == 1) ? H / 2 : 2 * H;
-  g.OW = (kind == 0) ? W : (kind == 1) ? W / 2 : 2 * W;
+  g.OH = (kind == 1) ? H / 2 : (kind == 2) ? 2 * H : H;
+  g.OW = (kind == 1) ? W / 2 : (kind == 2) ? 2 * W : W;
   const int npix = g.Hb * g.Wb;
   g.MT = (kind == 1) ? 64 : (npix >= 256 ? 128 : 64);
   int tw = g.Wb < ((kind == 1) ? 8 : 16) ? g.Wb : ((kind == 1) ? 8 : 16);
@@ -88,7 +88,7 @@ ConvGeo conv_geo(int kind, int H, int W, int Cout) {
   g.tiles_x = g.Wb / tw;
   g.tiles_per_img = (g.Hb / th) * g.tiles_x;
   const int s = (kind == 1) ? 2 : 1;
-  const int halo = (kind == 2) ? 1 : 2;
+  const int halo = (kind == 2) ? 1 : (kind == 3) ? 0 : 2;
   g.hth = th * s + halo;
   g.htw = tw * s + halo;
   g.pout = g.tiles_per_img * (kind == 2 ? 4 : 1);
@@ -111,6 +111,7 @@ struct ConvCall {
   const int* step_ptr; int step_off;
   float* y; float* stats_out;
   int B, H, W;
+  const float* res; int no_silu;
 };
 
 template <int MB, int KIND, int KC>
@@ -122,10 +123,10 @@ int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     attr_done = true;
   }
   const int cls = KIND == 0 ? (MB == 2 ? DM_K_CONV3_128 : DM_K_CONV3_64)
-                            : KIND == 1 ? DM_K_DOWN : (MB == 2 ? DM_K_UP_128 : DM_K_UP_64);
+                            : KIND == 1 ? DM_K_DOWN : KIND == 3 ? DM_K_ATTN : (MB == 2 ? DM_K_UP_128 : DM_K_UP_64);
   const double opix = (double)a.B * a.Hb * a.Wb * (KIND == 2 ? 4 : 1);
   const double ipix = (double)a.B * a.H * a.W;
-  const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : 4;
+  const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : KIND == 3 ? 1 : 4;
   const int cin = a.C1 + a.C2;
   ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 4.0 * (ipix * cin + opix * a.Cout + taps * (KIND == 2 ? 4 : 1) * cin * a.Cout));
   hipLaunchKernelGGL((conv_mfma_kernel<MB, KIND, KC>), grid, dim3(256), lds, s, a);
@@ -135,7 +136,7 @@ int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
 
 int launch_conv(const ConvCall& c, hipStream_t s) {
   const int cin = c.c1 + c.c2;
-  if (c.kind < 0 || c.kind > 2) return fail("conv: unknown kind %d", c.kind);
+  if (c.kind < 0 || c.kind > 3) return fail("conv: unknown kind %d", c.kind);
   if (c.c1 % 64 || c.c2 % 64 || c.cout % 64) return fail("conv: channel counts must be multiples of 64 (got %d+%d -> %d)", c.c1, c.c2, c.cout);
   if (c.cout != 64 && c.cout != 128 && c.cout != 256 && c.cout != 512 && c.stats_out)
     return fail("conv: GroupNorm(8) statistics need Cout in {64,128,256,512} (got %d)", c.cout);
@@ -156,6 +157,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   a.mg_htw = (unsigned)((0x100000000ull + g.htw - 1) / g.htw);
   a.mg_hth = (unsigned)((0x100000000ull + g.hth - 1) / g.hth);
   a.pout = g.pout;
+  a.res = c.res; a.tf_silu = c.no_silu ? 0 : 1;
 #ifdef DM_STAMPS
   a.stamps = g_stamps;
 #endif
@@ -171,11 +173,12 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   (void)cin;
   if (c.kind == 0) return g.MT == 128 ? launch_conv_t<2, 0, 64>(a, grid, lds, s) : launch_conv_t<1, 0, 64>(a, grid, lds, s);
   if (c.kind == 2) return g.MT == 128 ? launch_conv_t<2, 2, 64>(a, grid, lds, s) : launch_conv_t<1, 2, 64>(a, grid, lds, s);
+  if (c.kind == 3) return g.MT == 128 ? launch_conv_t<2, 3, 64>(a, grid, lds, s) : launch_conv_t<1, 3, 64>(a, grid, lds, s);
   return launch_conv_t<1, 1, 32>(a, grid, lds, s);
 }
 
 size_t conv_packed_floats(int kind, int cin, int cout) {
-  const int taps = kind == 0 ? 9 : 16;  // KIND 2: 4 parities x 4 taps
+  const int taps = kind == 0 ? 9 : kind == 3 ? 1 : 16;  // KIND 2: 4 parities x 4 taps
   return (size_t)taps * cin * cout;
 }
 
@@ -619,6 +622,16 @@ int dm_unet_profile(dm_unet* m, const float* packed, float* x, const int64_t* t_
   return 0;
 }
 
+int dm_postprocess(const float* x_dev, float* out_f32_dev, unsigned char* out_u8_dev, size_t count, void* stream) {
+  if (!x_dev || (!out_f32_dev && !out_u8_dev)) return fail("dm_postprocess: null argument");
+  if (count == 0) return 0;
+  size_t blocks = (count + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x_dev, out_f32_dev, out_u8_dev, count);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int dm_class_embed(const float* table_dev, int num_rows, int E, const float* w1, const float* b1, const float* w2,
                    const float* b2, const int64_t* labels_dev, int n, float* out_dev, void* stream) {
   if (!table_dev || !w1 || !b1 || !w2 || !b2 || !labels_dev || !out_dev) return fail("dm_class_embed: null argument");
@@ -637,12 +650,12 @@ size_t dm_conv_packed_floats(int kind, int cin, int cout) { return conv_packed_f
 
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev, void* stream) {
   if (!w_dev || !packed_dev) return fail("dm_pack_conv_weight: null argument");
-  if (kind < 0 || kind > 2) return fail("unknown conv kind %d", kind);
+  if (kind < 0 || kind > 3) return fail("unknown conv kind %d", kind);
   return pack_conv(kind, w_dev, cin, cout, packed_dev, (hipStream_t)stream);
 }
 
 int dm_conv_stats_partials(int kind, int H, int W) {
-  if (kind < 0 || kind > 2 || !is_pow2(H) || !is_pow2(W)) return 0;
+  if (kind < 0 || kind > 3 || !is_pow2(H) || !is_pow2(W)) return 0;
   return conv_geo(kind, H, W, 64).pout;
 }
 

@@ -26,6 +26,7 @@ __device__ __forceinline__ float dm_silu(float v) {
 // ------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on fp32 MFMA.
 //   KIND 0: Conv2d 3x3 s1 p1      KIND 1: Conv2d 4x4 s2 p1      KIND 2: ConvTranspose2d 4x4 s2 p1
+//   KIND 3: Conv2d 1x1 (attention qkv / proj; optional residual add)
 // GEMM view: M = output pixels (tile of MT = 64*MB pixels per workgroup), N = 64 output
 // channels per workgroup (blockIdx.y), K = taps x input channels, walked as
 // [channel chunk of KC][tap][8 channels].
@@ -53,6 +54,8 @@ struct ConvArgs {
   const float* temb;      // null or per-channel add (after SiLU)
   const int* step_ptr;    // null or device step counter (sampling loop)
   float* stats_out;       // null or [B][pout][8][2]
+  const float* res;       // null or residual [B,OH,OW,Cout] added to the output (may alias y)
+  int tf_silu;            // input transform applies SiLU after GroupNorm (0: GroupNorm only)
   float cnt_in;           // elements per input partial
   int pin;
   int temb_stride;        // per-image stride of temb (0 = shared)
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   constexpr int MT = 64 * MB;
   constexpr int RS = KC + 4;  // LDS row stride (floats): 16-B skew between consecutive pixels
   constexpr int S = (KIND == 1) ? 2 : 1;
-  constexpr int NTY = (KIND == 0) ? 3 : (KIND == 1) ? 4 : 2;
+  constexpr int NTY = (KIND == 0) ? 3 : (KIND == 1) ? 4 : (KIND == 2) ? 2 : 1;
   constexpr int NT = NTY * NTY;
   constexpr int NJ = KC / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   const int tin = t % p.tiles_per_img;
   const int y0 = (tin / p.tiles_x) << p.th_log;
   const int x0 = (tin % p.tiles_x) << p.tw_log;
-  const int hy0 = (KIND == 0) ? y0 - 1 : (KIND == 1) ? 2 * y0 - 1 : y0 - 1 + py;
-  const int hx0 = (KIND == 0) ? x0 - 1 : (KIND == 1) ? 2 * x0 - 1 : x0 - 1 + px;
+  const int hy0 = (KIND == 0) ? y0 - 1 : (KIND == 1) ? 2 * y0 - 1 : (KIND == 2) ? y0 - 1 + py : y0;
+  const int hx0 = (KIND == 0) ? x0 - 1 : (KIND == 1) ? 2 * x0 - 1 : (KIND == 2) ? x0 - 1 + px : x0;
   const int hth = p.hth, htw = p.htw;
   const int NP = p.ni * hth * htw;
 
@@ -223,10 +226,10 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
             const float4 sc = *reinterpret_cast<const float4*>(s_scale + tofs);
             const float4 be = *reinterpret_cast<const float4*>(s_beta + c);
             const float4 te = *reinterpret_cast<const float4*>(s_temb + tofs);
-            w.x = dm_silu((w.x - mu.x) * sc.x + be.x) + te.x;
-            w.y = dm_silu((w.y - mu.y) * sc.y + be.y) + te.y;
-            w.z = dm_silu((w.z - mu.z) * sc.z + be.z) + te.z;
-            w.w = dm_silu((w.w - mu.w) * sc.w + be.w) + te.w;
+            w.x = (w.x - mu.x) * sc.x + be.x; w.y = (w.y - mu.y) * sc.y + be.y;
+            w.z = (w.z - mu.z) * sc.z + be.z; w.w = (w.w - mu.w) * sc.w + be.w;
+            if (p.tf_silu) { w.x = dm_silu(w.x); w.y = dm_silu(w.y); w.z = dm_silu(w.z); w.w = dm_silu(w.w); }
+            w.x += te.x; w.y += te.y; w.z += te.z; w.w += te.w;
           }
           *reinterpret_cast<float4*>(tile + lofs) = w;
         }
@@ -294,8 +297,8 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mb][r] += bv;
-  const int OW = (KIND == 0) ? p.W : (KIND == 1) ? (p.W >> 1) : (p.W << 1);
-  const int OH = (KIND == 0) ? p.H : (KIND == 1) ? (p.H >> 1) : (p.H << 1);
+  const int OW = (KIND == 1) ? (p.W >> 1) : (KIND == 2) ? (p.W << 1) : p.W;
+  const int OH = (KIND == 1) ? (p.H >> 1) : (KIND == 2) ? (p.H << 1) : p.H;
   constexpr int ORS = 68;                 // output staging row stride (floats)
   float* otile = smem;                    // [MT][ORS]
   float* sred = smem + MT * ORS;          // [4 waves][NSW][4]
@@ -394,8 +397,13 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
     if (n < p.B) {
       const int oy = (KIND == 2) ? 2 * y + py : y;
       const int ox = (KIND == 2) ? 2 * x + px : x;
-      const float4 v = *reinterpret_cast<const float4*>(otile + m * ORS + c4 * 4);
-      *reinterpret_cast<float4*>(p.y + (((size_t)n * OH + oy) * OW + ox) * p.Cout + blockIdx.y * 64 + c4 * 4) = v;
+      float4 v = *reinterpret_cast<const float4*>(otile + m * ORS + c4 * 4);
+      const size_t o = (((size_t)n * OH + oy) * OW + ox) * p.Cout + blockIdx.y * 64 + c4 * 4;
+      if (p.res) {
+        const float4 r = *reinterpret_cast<const float4*>(p.res + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4*>(p.y + o) = v;
     }
   }
   DM_STAMP(3);
@@ -408,9 +416,9 @@ __global__ void pack_conv_weight_kernel(int kind, const float* __restrict__ w, i
                                         float* __restrict__ out, size_t total) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const int nty = kind == 0 ? 3 : kind == 1 ? 4 : 2;
+  const int nty = kind == 0 ? 3 : kind == 1 ? 4 : kind == 2 ? 2 : 1;
   const int nt = nty * nty;
-  const int ks = kind == 0 ? 3 : 4;
+  const int ks = kind == 0 ? 3 : kind == 3 ? 1 : 4;
   size_t r = idx;
   const int e = r & 3; r >>= 2;
   const int lane = r & 63; r >>= 6;
@@ -684,6 +692,18 @@ __global__ __launch_bounds__(256) void class_embed_kernel(const float* __restric
     float s = 0.f;
     for (int i = 0; i < E; ++i) s += wr[i] * hbuf[i];
     out[(size_t)n * E + o] = s + b2[o];
+  }
+}
+
+// Post-processing of finished samples (diffusion/sample.py:117-119): (x + 1) / 2, clamp to [0,1];
+// optionally quantised to uint8 as torchvision.utils.save_image does (v*255 + 0.5, clamp, truncate).
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ x, float* __restrict__ out_f,
+                                                          unsigned char* __restrict__ out_u8, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    float v = (x[i] + 1.0f) / 2.0f;
+    v = fminf(fmaxf(v, 0.0f), 1.0f);
+    if (out_f) out_f[i] = v;
+    if (out_u8) out_u8[i] = (unsigned char)fminf(fmaxf(v * 255.0f + 0.5f, 0.0f), 255.0f);
   }
 }
 

@@ -103,6 +103,12 @@ int dm_sample(dm_unet* m, const float* packed_dev, float* x_dev, int B, int H, i
               const float* noise_dev, const float* cond_dev, float guidance,
               void* workspace_dev, size_t workspace_bytes, int use_graph, void* stream);
 
+/* ---- post-processing: replaces `(samples + 1) / 2; clamp(0, 1)` (diffusion/sample.py:117-119).
+ * out_f32_dev and/or out_u8_dev (uint8 = trunc(v*255 + 0.5), torchvision save_image's rule);
+ * either may be NULL.  out_f32_dev may alias x_dev. */
+int dm_postprocess(const float* x_dev, float* out_f32_dev, unsigned char* out_u8_dev,
+                   size_t count, void* stream);
+
 /* ---- class embedding: replaces ClassConditioner.forward (diffusion/conditioning.py:39-55):
  * out[n] = Linear2(SiLU(Linear1(table[labels[n]]))).  table [num_rows,E]; w1,w2 [E,E]; b1,b2 [E];
  * labels int64[n] in [0,num_rows); out [n,E].  Feeds dm_unet_forward / dm_sample's cond_dev. */
@@ -124,7 +130,8 @@ enum {
   DM_K_FINAL = 6,     /* final_conv_kernel                                  (HBM-bound) */
   DM_K_TIME = 7,      /* time_embed_kernel                                              */
   DM_K_STEP = 8,      /* sampler_step_kernel                                (HBM-bound) */
-  DM_K_COUNT = 9
+  DM_K_ATTN = 9,      /* attention block: 1x1 qkv/proj convs, QK^T / PV GEMMs, softmax  */
+  DM_K_COUNT = 10
 };
 int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int64_t* t_dev,
                     const float* coef_host, int B, int H, int W, void* workspace_dev,
@@ -133,7 +140,8 @@ int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int
 
 /* ---- single operators (NHWC), exported for the per-kernel parity tests ------------------
  * kind: 0 = Conv2d 3x3 pad 1 (model.py:42,45,47,99,102), 1 = Conv2d 4x4 stride 2 pad 1
- * (model.py:46), 2 = ConvTranspose2d 4x4 stride 2 pad 1 (model.py:43). */
+ * (model.py:46), 2 = ConvTranspose2d 4x4 stride 2 pad 1 (model.py:43), 3 = Conv2d 1x1 (build-defined
+ * attention block). */
 size_t dm_conv_packed_floats(int kind, int cin, int cout);
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev,
                         void* stream);

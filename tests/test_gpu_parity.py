@@ -1,6 +1,8 @@
 """End-to-end parity (GPU) of the drop-in classes against the golden fixtures produced by the
 reference CPU sampler, and against the CPU oracle.  Tolerances are north_star's: per-step eps
 max-abs <= 1e-4 (fp32), final-image PSNR >= 40 dB."""
+import os
+
 import pytest
 import torch
 
@@ -206,3 +208,32 @@ def test_wide_unet_64x64x3_c256_matches_reference():
     assert (eps - G["eps_tb"]).abs().max().item() <= EPS_TOL
     # batch independence holds for the wide geometry too
     assert torch.equal(m(x[1:2].contiguous(), torch.tensor(250)).cpu(), m(x, torch.tensor(250)).cpu()[1:2])
+
+
+def test_driver_checkpoint_ema_override_and_postprocess(tmp_path, ckpt, golden):
+    """sample.py:61-85 + :117-119: reference-format .pth (weights_only load), EMA override, [0,1] output."""
+    from diffusion_model_amd import sample as S
+    sdict = ckpt["model_state_dict"]
+    ema = {k: v * 1.01 for k, v in sdict.items()}           # a distinguishable shadow copy
+    path = os.path.join(tmp_path, "ck.pth")
+    torch.save({"epoch": 3, "model_state_dict": sdict, "ema_shadow": ema, "loss": 0.0}, path)
+    cfg = S.get_default_config()
+    cfg["checkpoint_path"] = path
+    drv = S.DDPMSampler(cfg, sampler_type="ddim", num_inference_steps=5, eta=0.0)
+    for name, p in drv.model.named_parameters():
+        assert torch.equal(p.detach().cpu(), ema[name]), name
+    x = golden["fwd_x"]
+    with torch.no_grad():
+        ref = O.unet_forward(ema, x, torch.tensor(500))
+    assert (drv.model(x.to(DEV), torch.tensor(500)).cpu() - ref).abs().max().item() <= EPS_TOL  # packed weights follow the swap
+    torch.manual_seed(1)
+    out = drv.generate_samples(num_samples=3, progress_bar=False)
+    torch.manual_seed(1)
+    raw = O.sample(ema, O.make_schedule(), (3, 1, 32, 32), 5, 0.0)
+    refp = torch.clamp((raw + 1) / 2, 0, 1)
+    assert out.min().item() >= 0.0 and out.max().item() <= 1.0
+    assert (out.cpu() - refp).abs().max().item() <= 1e-4
+    u8 = S.postprocess(raw.to(DEV), uint8=True).cpu()
+    assert torch.equal(u8, refp.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8))
+    drv.save_samples(out, os.path.join(tmp_path, "g.png"), nrow=2)
+    assert open(os.path.join(tmp_path, "g.png"), "rb").read(8) == b"\x89PNG\r\n\x1a\n"
