@@ -203,8 +203,12 @@ struct GraphEntry {
   hipGraphExec_t exec;
 };
 
+struct AttnOff { size_t ng, nb, qkv, qkvb, proj, projb; };
+
 struct dm_unet {
   int Cin, Cout, C, E;
+  int attn;            // build-defined attention blocks at 1/4 resolution (after down2 and up1)
+  AttnOff att[2];
   size_t o_freqs, o_tm1w, o_tm1b, o_tm2w, o_tm2b, o_initw, o_initb;
   BlockOff blk[6];
   size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb;
@@ -276,6 +280,54 @@ int launch_time_embed(const dm_unet* m, const float* P, const int64_t* t, int nt
   return 0;
 }
 
+int launch_bgemm(bool bkn, const GemmArgs& g, int batch, hipStream_t s) {
+  if (g.M % 64 || g.N % 64 || g.K % 32) return fail("bgemm: M,N %% 64 and K %% 32 required (got %d,%d,%d)", g.M, g.N, g.K);
+  ProfScope ps(DM_K_ATTN, s, 2.0 * batch * g.M * (double)g.N * g.K, 4.0 * batch * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+  dim3 grid(g.N / 64, g.M / 64, batch);
+  if (bkn) hipLaunchKernelGGL(bgemm_mfma_kernel<true>, grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(bgemm_mfma_kernel<false>, grid, dim3(256), 0, s, g);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Build-defined attention block on X [B,h,w,C] in place:
+//   X += proj( softmax(Q K^T / sqrt(C)) V ),  [Q,K,V] = qkv_1x1( GroupNorm8(X) )
+// GroupNorm statistics of X come as partials from the conv that produced it.
+int attention_block(const dm_unet* m, const float* P, int which, float* X, const float* stats, int pin, float cnt,
+                    const Workspace& w, int B, int h, int ww, int Hfull, int Wfull, hipStream_t s) {
+  const int C = m->C, T = h * ww;
+  const AttnOff& o = m->att[which];
+  const size_t full = (size_t)B * Hfull * Wfull * C;
+  if ((size_t)B * T * 4 * C > full || (size_t)B * T * T > full) return fail("attention: workspace too small for %d tokens", T);
+  if (T % 64) return fail("attention: token count %d must be a multiple of 64", T);
+  float* QKV = w.T1;
+  float* O = w.T1 + (size_t)B * T * 3 * C;
+  float* S = w.T2;
+  ConvCall c;
+  memset(&c, 0, sizeof c);
+  c.kind = 3; c.x1 = X; c.c1 = C; c.wp = P + o.qkv; c.bias = P + o.qkvb; c.cout = 3 * C; c.y = QKV;
+  c.stats_in = stats; c.pin = pin; c.cnt_in = cnt; c.gamma = P + o.ng; c.beta = P + o.nb; c.no_silu = 1;
+  c.B = B; c.H = h; c.W = ww;
+  if (launch_conv(c, s)) return 1;
+  GemmArgs g;
+  g.A = QKV; g.Bm = QKV + C; g.C = S; g.M = T; g.N = T; g.K = C; g.lda = 3 * C; g.ldb = 3 * C; g.ldc = T;
+  g.sA = (size_t)T * 3 * C; g.sB = g.sA; g.sC = (size_t)T * T; g.alpha = 1.0f / sqrtf((float)C);
+  if (launch_bgemm(false, g, B, s)) return 1;
+  {
+    const size_t rows = (size_t)B * T;
+    ProfScope ps(DM_K_ATTN, s, 5.0 * rows * T, 8.0 * rows * T);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, S, rows, T);
+    HIP_TRY(hipGetLastError());
+  }
+  g.A = S; g.Bm = QKV + 2 * C; g.C = O; g.M = T; g.N = C; g.K = T; g.lda = T; g.ldb = 3 * C; g.ldc = C;
+  g.sA = (size_t)T * T; g.sB = (size_t)T * 3 * C; g.sC = (size_t)T * C; g.alpha = 1.0f;
+  if (launch_bgemm(true, g, B, s)) return 1;
+  memset(&c, 0, sizeof c);
+  c.kind = 3; c.x1 = O; c.c1 = C; c.wp = P + o.proj; c.bias = P + o.projb; c.cout = C; c.y = X; c.res = X;
+  c.B = B; c.H = h; c.W = ww;
+  return launch_conv(c, s);
+}
+
 // One denoiser evaluation (everything after the time embedding): model.py:135-151.
 // heads: [.., 6, C] table; heads_img_stride = 6*C when every image has its own timestep
 // (training-style [B] t) else 0; in the sampling loop the table is indexed by the step
@@ -318,7 +370,11 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     return launch_conv(c, s);
   };
   if (block(0, w.A0, nullptr, H, W, false, w.D1, nullptr)) return 1;
-  if (block(1, w.D1, nullptr, H / 2, W / 2, false, w.D2, nullptr)) return 1;
+  if (block(1, w.D1, nullptr, H / 2, W / 2, false, w.D2, m->attn ? w.SA : nullptr)) return 1;
+  if (m->attn) {
+    const ConvGeo pg = conv_geo(1, H / 2, W / 2, C);
+    if (attention_block(m, P, 0, w.D2, w.SA, pg.pout, pg.cnt_out, w, B, H / 4, W / 4, H, W, s)) return 1;
+  }
   if (block(2, w.D2, nullptr, H / 4, W / 4, false, w.D3, nullptr)) return 1;
   // bottleneck (model.py:98-103,143)
   base(0, w.D3, C, nullptr, 0, m->o_b0, m->o_b0b, w.BT0, w.SA, H / 8, W / 8);
@@ -327,7 +383,11 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   with_tf(w.SA, 0, H / 8, W / 8, m->o_bg, m->o_bb);
   if (launch_conv(c, s)) return 1;
   // up path: channel concat [upstream, skip] (model.py:146-148) handled by two input pointers
-  if (block(3, w.BT, w.D3, H / 8, W / 8, true, w.U1, nullptr)) return 1;
+  if (block(3, w.BT, w.D3, H / 8, W / 8, true, w.U1, m->attn ? w.SA : nullptr)) return 1;
+  if (m->attn) {
+    const ConvGeo pg = conv_geo(2, H / 8, W / 8, C);
+    if (attention_block(m, P, 1, w.U1, w.SA, pg.pout, pg.cnt_out, w, B, H / 4, W / 4, H, W, s)) return 1;
+  }
   if (block(4, w.U1, w.D2, H / 4, W / 4, true, w.U2, nullptr)) return 1;
   if (block(5, w.U2, w.D1, H / 2, W / 2, true, w.A0, w.SA)) return 1;
   {  // final_conv (model.py:111-115,151)
@@ -368,6 +428,13 @@ const char* dm_last_error(void) { return g_err.c_str(); }
 int dm_version(void) { return 1; }
 
 int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_channels, int time_emb_dim) {
+  return dm_unet_create_ex(out, in_channels, out_channels, model_channels, time_emb_dim, 0);
+}
+
+int dm_unet_num_params(const dm_unet* m) { return m ? DM_UNET_NUM_PARAMS + (m->attn ? 12 : 0) : 0; }
+
+int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int model_channels, int time_emb_dim,
+                      int attention) {
   if (!out) return fail("dm_unet_create: null out");
   if (in_channels < 1 || in_channels > 4 || out_channels < 1 || out_channels > 4)
     return fail("in/out channels must be in 1..4 (got %d, %d)", in_channels, out_channels);
@@ -377,6 +444,7 @@ int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_c
     return fail("time_emb_dim must be even, in 4..1024 (got %d)", time_emb_dim);
   dm_unet* m = new dm_unet();
   m->Cin = in_channels; m->Cout = out_channels; m->C = model_channels; m->E = time_emb_dim;
+  m->attn = attention ? 1 : 0;
   const int C = m->C, E = m->E;
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
@@ -397,6 +465,13 @@ int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_c
   m->o_b3 = take(conv_packed_floats(0, C, C)); m->o_b3b = take(C);
   m->o_fg = take(C); m->o_fb = take(C);
   m->o_fw = take((size_t)m->Cout * C); m->o_fwb = take(m->Cout);
+  if (m->attn)
+    for (int k = 0; k < 2; ++k) {
+      AttnOff& a = m->att[k];
+      a.ng = take(C); a.nb = take(C);
+      a.qkv = take(conv_packed_floats(3, C, 3 * C)); a.qkvb = take(3 * C);
+      a.proj = take(conv_packed_floats(3, C, C)); a.projb = take(C);
+    }
   m->total = off;
   *out = m;
   return 0;
@@ -416,7 +491,7 @@ size_t dm_unet_packed_floats(const dm_unet* m) { return m ? m->total : 0; }
 int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const float* freqs_dev,
                          float* packed, void* stream) {
   if (!m || !p || !packed) return fail("dm_unet_pack_weights: null argument");
-  if (nparams != DM_UNET_NUM_PARAMS) return fail("expected %d parameter tensors, got %d", DM_UNET_NUM_PARAMS, nparams);
+  if (nparams != dm_unet_num_params(m)) return fail("expected %d parameter tensors, got %d", dm_unet_num_params(m), nparams);
   for (int i = 0; i < nparams; ++i) if (!p[i]) return fail("parameter %d is null", i);
   hipStream_t s = (hipStream_t)stream;
   const int C = m->C, E = m->E;
@@ -453,7 +528,14 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
   for (int k = 3; k < 6; ++k) if (do_block(k)) return 1;
   if (copy(m->o_fg, p[i++], C) || copy(m->o_fb, p[i++], C) ||
       copy(m->o_fw, p[i++], (size_t)m->Cout * C) || copy(m->o_fwb, p[i++], m->Cout)) return 1;
-  if (i != DM_UNET_NUM_PARAMS) return fail("internal: consumed %d params", i);
+  if (m->attn)
+    for (int k = 0; k < 2; ++k) {
+      const AttnOff& a = m->att[k];
+      if (copy(a.ng, p[i++], C) || copy(a.nb, p[i++], C) ||
+          pack_conv(3, p[i++], C, 3 * C, packed + a.qkv, s) || copy(a.qkvb, p[i++], 3 * C) ||
+          pack_conv(3, p[i++], C, C, packed + a.proj, s) || copy(a.projb, p[i++], C)) return 1;
+    }
+  if (i != dm_unet_num_params(m)) return fail("internal: consumed %d params", i);
   return 0;
 }
 

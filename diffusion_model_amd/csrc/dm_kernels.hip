@@ -695,6 +695,89 @@ __global__ __launch_bounds__(256) void class_embed_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Attention block (build-defined, BASELINE configs[4]): batched fp32-MFMA GEMM and row softmax.
+// C[b] = alpha * A[b] (MxK, row-major, lda) * B[b], with B given as [N][K] (BKN = false: Q K^T)
+// or [K][N] (BKN = true: P V).  64x64 tile per workgroup, 4 waves x one 32x32 accumulator,
+// K chunks of 32 staged in LDS k-contiguous for both operands (same b128 fragment scheme as the
+// conv kernel).  M, N multiples of 64, K multiple of 32.  <1 % of the widened model's FLOPs.
+struct GemmArgs {
+  const float* A; const float* Bm; float* C;
+  int M, N, K, lda, ldb, ldc;
+  size_t sA, sB, sC;
+  float alpha;
+};
+
+template <bool BKN>
+__global__ __launch_bounds__(256) void bgemm_mfma_kernel(const GemmArgs g) {
+  constexpr int RS = 36;
+  __shared__ __attribute__((aligned(16))) float As[64 * RS];
+  __shared__ __attribute__((aligned(16))) float Bs[64 * RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const float* A = g.A + blockIdx.z * g.sA;
+  const float* Bm = g.Bm + blockIdx.z * g.sB;
+  float* C = g.C + blockIdx.z * g.sC;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k0 = 0; k0 < g.K; k0 += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + u * 256;
+      const int row = idx >> 3, c4 = idx & 7;
+      *reinterpret_cast<float4*>(As + row * RS + c4 * 4) =
+          *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * g.lda + k0 + c4 * 4);
+      if (!BKN) {
+        *reinterpret_cast<float4*>(Bs + row * RS + c4 * 4) =
+            *reinterpret_cast<const float4*>(Bm + (size_t)(n0 + row) * g.ldb + k0 + c4 * 4);
+      } else {
+        const int k = idx >> 4, n4 = idx & 15;
+        const float4 v = *reinterpret_cast<const float4*>(Bm + (size_t)(k0 + k) * g.ldb + n0 + n4 * 4);
+        Bs[(n4 * 4 + 0) * RS + k] = v.x; Bs[(n4 * 4 + 1) * RS + k] = v.y;
+        Bs[(n4 * 4 + 2) * RS + k] = v.z; Bs[(n4 * 4 + 3) * RS + k] = v.w;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 a = *reinterpret_cast<const float4*>(As + (wm * 32 + (lane & 31)) * RS + j * 8 + 4 * h);
+      const float4 b = *reinterpret_cast<const float4*>(Bs + (wn * 32 + (lane & 31)) * RS + j * 8 + 4 * h);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    C[(size_t)row * g.ldc + n0 + wn * 32 + (lane & 31)] = g.alpha * acc[r];
+  }
+}
+
+// In-place softmax over rows of length n (one wave per row).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, size_t rows, int n) {
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  float* r = s + row * n;
+  float mx = -INFINITY;
+  for (int i = lane; i < n; i += 64) mx = fmaxf(mx, r[i]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    const float e = expf(r[i] - mx);
+    r[i] = e;
+    sum += e;
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float inv = 1.0f / sum;
+  for (int i = lane; i < n; i += 64) r[i] *= inv;
+}
+
 // Post-processing of finished samples (diffusion/sample.py:117-119): (x + 1) / 2, clamp to [0,1];
 // optionally quantised to uint8 as torchvision.utils.save_image does (v*255 + 0.5, clamp, truncate).
 __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ x, float* __restrict__ out_f,

@@ -56,13 +56,28 @@ class Block(nn.Module):
                            "call the model, not the sub-module")
 
 
+class AttnBlock(nn.Module):
+    """Parameter container of the BUILD-DEFINED self-attention block (no reference counterpart,
+    model.py:70): GroupNorm(8) -> 1x1 qkv -> softmax(QK^T/sqrt(C))V -> 1x1 proj -> residual."""
+
+    def __init__(self, ch):
+        super().__init__()
+        self.norm = nn.GroupNorm(8, ch)
+        self.qkv = nn.Conv2d(ch, 3 * ch, 1)
+        self.proj = nn.Conv2d(ch, ch, 1)
+
+    def forward(self, x):
+        raise RuntimeError("AttnBlock is evaluated inside UNetMini.forward")
+
+
 class UNetMini(nn.Module):
     """diffusion/model.py:67-151.  ``forward(x[B,Cin,H,W], timesteps)`` -> eps[B,Cout,H,W];
     ``timesteps`` is a 0-dim int64 tensor (sampling) or a [B] tensor (training style)."""
 
     def __init__(self, image_size=28, in_channels=1, out_channels=1, model_channels=64,
-                 time_emb_dim=128):
+                 time_emb_dim=128, attention=False):
         super().__init__()
+        self.attention = bool(attention)  # build-defined extension; False = the reference model
         self.device = get_device()
         self.image_size = image_size
         self.in_channels = in_channels
@@ -93,6 +108,9 @@ class UNetMini(nn.Module):
             nn.SiLU(),
             nn.Conv2d(model_channels, out_channels, 1),
         )
+        if self.attention:  # registered last: the reference's 88 tensors keep their order
+            self.attn_down = AttnBlock(model_channels)
+            self.attn_up = AttnBlock(model_channels)
         self.to(self.device)
         self._handle = None
         self._packed = None
@@ -111,15 +129,16 @@ class UNetMini(nn.Module):
     def _native(self):
         if self._handle is None:
             h = C.c_void_p()
-            _lib.check(_lib.lib().dm_unet_create(C.byref(h), self.in_channels, self.out_channels,
-                                                 self.model_channels, self.time_emb_dim))
+            _lib.check(_lib.lib().dm_unet_create_ex(C.byref(h), self.in_channels, self.out_channels,
+                                                    self.model_channels, self.time_emb_dim, int(self.attention)))
             self._handle = h
         return self._handle
 
     def _params_in_order(self):
         ps = list(self.parameters())
-        if len(ps) != 88:
-            raise RuntimeError(f"expected 88 parameter tensors, found {len(ps)}")
+        want = 100 if self.attention else 88
+        if len(ps) != want:
+            raise RuntimeError(f"expected {want} parameter tensors, found {len(ps)}")
         return ps
 
     def packed_weights(self):
@@ -138,9 +157,9 @@ class UNetMini(nn.Module):
                     raise RuntimeError("parameters must be contiguous fp32 tensors on one device")
             if self._packed is None or self._packed.device != dev:
                 self._packed = torch.empty(L.dm_unet_packed_floats(h), dtype=torch.float32, device=dev)
-            arr = (C.c_void_p * 88)(*[p.data_ptr() for p in ps])
+            arr = (C.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
             freqs = self.time_mlp[0].frequencies().to(dev)
-            _lib.check(L.dm_unet_pack_weights(h, arr, 88, _lib.ptr(freqs), _lib.ptr(self._packed),
+            _lib.check(L.dm_unet_pack_weights(h, arr, len(ps), _lib.ptr(freqs), _lib.ptr(self._packed),
                                               torch.cuda.current_stream(dev).cuda_stream))
             self._pack_key = key
             self._freqs_keepalive = freqs

@@ -41,6 +41,14 @@ int dm_version(void);
 /* ---- model container: replaces UNetMini.__init__ (diffusion/model.py:72-118) ---------- */
 int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_channels,
                    int time_emb_dim);
+/* attention != 0 adds the BUILD-DEFINED self-attention blocks of BASELINE configs[4] (no reference
+ * counterpart: model.py:70 "No attention layers"): GroupNorm8 -> 1x1 qkv -> single-head
+ * softmax(QK^T/sqrt(C))V over the (H/4)x(W/4) tokens -> 1x1 proj -> residual, applied to down2's
+ * output and to up1's output.  12 more parameter tensors follow the 88, for attn_down then
+ * attn_up: norm.weight, norm.bias, qkv.weight [3C,C,1,1], qkv.bias, proj.weight [C,C,1,1], proj.bias. */
+int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int model_channels,
+                      int time_emb_dim, int attention);
+int dm_unet_num_params(const dm_unet* m);
 void dm_unet_destroy(dm_unet* m);
 
 /* Size (in floats) of the packed weight blob for this geometry. */

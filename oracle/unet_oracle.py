@@ -67,6 +67,17 @@ def block_forward(sd: Dict[str, Tensor], p: str, x: Tensor, t: Tensor, up: bool)
     return F.conv2d(h, sd[p + "transform.weight"], sd[p + "transform.bias"], stride=2, padding=1)
 
 
+def attention_block(sd: Dict[str, Tensor], p: str, x: Tensor) -> Tensor:
+    """BUILD-DEFINED (no reference counterpart; parity unpinned): x + proj(softmax(QK^T/sqrt(C))V),
+    [Q,K,V] = qkv_1x1(GroupNorm8(x)), single head over the H*W tokens."""
+    B, C, H, W = x.shape
+    h = F.group_norm(x, 8, sd[p + "norm.weight"], sd[p + "norm.bias"], eps=1e-5)
+    q, k, v = F.conv2d(h, sd[p + "qkv.weight"], sd[p + "qkv.bias"]).reshape(B, 3, C, H * W).unbind(1)
+    s = torch.einsum("bct,bcs->bts", q, k) / math.sqrt(C)
+    o = torch.einsum("bts,bcs->bct", s.softmax(-1), v).reshape(B, C, H, W)
+    return x + F.conv2d(o, sd[p + "proj.weight"], sd[p + "proj.bias"])
+
+
 def unet_forward(sd: Dict[str, Tensor], x: Tensor, timesteps: Tensor,
                  cond_emb: Optional[Tensor] = None, taps: Optional[dict] = None) -> Tensor:
     """model.py:120-151.  ``cond_emb`` ([B,E], added to the time embedding) is the
@@ -82,11 +93,16 @@ def unet_forward(sd: Dict[str, Tensor], x: Tensor, timesteps: Tensor,
         taps["init"] = h
     d1 = block_forward(sd, "down1.", h, t, False)
     d2 = block_forward(sd, "down2.", d1, t, False)
+    attn = "attn_down.qkv.weight" in sd  # build-defined extension
+    if attn:
+        d2 = attention_block(sd, "attn_down.", d2)
     d3 = block_forward(sd, "down3.", d2, t, False)
     b = F.conv2d(d3, sd["bottleneck.0.weight"], sd["bottleneck.0.bias"], padding=1)
     b = F.silu(F.group_norm(b, 8, sd["bottleneck.1.weight"], sd["bottleneck.1.bias"], eps=1e-5))
     b = F.conv2d(b, sd["bottleneck.3.weight"], sd["bottleneck.3.bias"], padding=1)
     u1 = block_forward(sd, "up1.", torch.cat([b, d3], dim=1), t, True)
+    if attn:
+        u1 = attention_block(sd, "attn_up.", u1)
     u2 = block_forward(sd, "up2.", torch.cat([u1, d2], dim=1), t, True)
     u3 = block_forward(sd, "up3.", torch.cat([u2, d1], dim=1), t, True)
     if taps is not None:

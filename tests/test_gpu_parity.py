@@ -237,3 +237,30 @@ def test_driver_checkpoint_ema_override_and_postprocess(tmp_path, ckpt, golden):
     assert torch.equal(u8, refp.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8))
     drv.save_samples(out, os.path.join(tmp_path, "g.png"), nrow=2)
     assert open(os.path.join(tmp_path, "g.png"), "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+
+
+@pytest.mark.parametrize("size,cin,C", [(32, 1, 64), (64, 3, 256)])
+def test_attention_unet_vs_oracle(size, cin, C):
+    """BASELINE configs[4]: widened UNet with self-attention at 1/4 resolution (16x16 = 256 tokens for
+    64x64).  The attention block is build-defined (parity unpinned by the reference): the oracle is
+    the CPU restatement oracle.attention_block inside the otherwise reference-pinned forward."""
+    d.set_seed(11)
+    m = d.UNetMini(image_size=size, in_channels=cin, out_channels=cin, model_channels=C, attention=True).eval()
+    assert len(list(m.parameters())) == 100 and list(m.state_dict().keys())[88].startswith("attn_down.")
+    with torch.no_grad():  # make the attention branch matter (default init gives a small residual)
+        for blk in (m.attn_down, m.attn_up):
+            blk.qkv.weight.mul_(4.0)
+            blk.proj.weight.mul_(4.0)
+    sdc = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    torch.manual_seed(12)
+    x = torch.randn(3, cin, size, size)
+    with torch.no_grad():
+        ref = O.unet_forward(sdc, x, torch.tensor(400))
+        plain = O.unet_forward({k: v for k, v in sdc.items() if not k.startswith("attn_")}, x, torch.tensor(400))
+    assert (ref - plain).abs().max().item() > 1e-2  # the attention blocks change the output
+    eps = m(x.to(DEV), torch.tensor(400)).cpu()
+    assert (eps - ref).abs().max().item() <= EPS_TOL
+    smp = d.DDIMSampler(d.DDPMScheduler(), num_inference_steps=4, eta=0.0)
+    out = smp.sample_from(m, x).cpu()
+    refs = O.sample(sdc, O.make_schedule(), x.shape, 4, 0.0, x_T=x)
+    assert (out - refs).abs().max().item() <= 1e-3
