@@ -132,9 +132,15 @@ def main():
                                    "tflops": fl[k] / (ms[k] * 1e-3) / 1e12, "alg_gbps": by[k] / (ms[k] * 1e-3) / 1e9}
         k = 1  # dominant: conv_mfma_kernel<2,0,64>
         ach = fl[k] / (ms[k] * 1e-3) / 1e12
+        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        if os.path.exists(tpath) and B == 1024:
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
         res["roofline"] = {"kernel": "conv_mfma_kernel<2,0,64> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)",
                            "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                           "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, B=1024)",
+                           "algorithmic_bytes_per_launch": by[k] / counts[k],
                            "avg_launch_us": 1e3 * ms[k] / counts[k], "flop_per_launch": fl[k] / counts[k],
                            "share_of_denoiser_time": ms[k] / tot_ms}
         res["kernels"] = per
