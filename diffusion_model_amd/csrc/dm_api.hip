@@ -122,13 +122,14 @@ int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
+  constexpr bool UP = (KIND == 2 || KIND == 4);
   const int cls = KIND == 0 ? (MB == 2 ? DM_K_CONV3_128 : DM_K_CONV3_64)
                             : KIND == 1 ? DM_K_DOWN : KIND == 3 ? DM_K_ATTN : (MB == 2 ? DM_K_UP_128 : DM_K_UP_64);
-  const double opix = (double)a.B * a.Hb * a.Wb * (KIND == 2 ? 4 : 1);
+  const double opix = (double)a.B * a.Hb * a.Wb * (UP ? 4 : 1);
   const double ipix = (double)a.B * a.H * a.W;
   const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : KIND == 3 ? 1 : 4;
   const int cin = a.C1 + a.C2;
-  ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 4.0 * (ipix * cin + opix * a.Cout + taps * (KIND == 2 ? 4 : 1) * cin * a.Cout));
+  ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 4.0 * (ipix * cin + opix * a.Cout + taps * (UP ? 4 : 1) * cin * a.Cout));
   hipLaunchKernelGGL((conv_mfma_kernel<MB, KIND, KC>), grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -144,7 +145,10 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   if (c.kind == 1 && (c.H < 2 || c.W < 2)) return fail("conv: stride-2 conv needs H,W >= 2");
   if (c.stats_in && c.c2) return fail("conv: input transform and channel concat are exclusive");
   if (c.B <= 0) return fail("conv: empty batch");
-  const ConvGeo g = conv_geo(c.kind, c.H, c.W, c.cout);
+  ConvGeo g = conv_geo(c.kind, c.H, c.W, c.cout);
+  // transposed conv with a single K chunk: all four output parities from one staged tile
+  const bool fused_up = c.kind == 2 && cin == 64;
+  if (fused_up) { g.hth += 1; g.htw += 1; }
   ConvArgs a;
   memset(&a, 0, sizeof a);
   a.x1 = c.x1; a.x2 = c.x2; a.wp = c.wp; a.bias = c.bias; a.y = c.y;
@@ -163,13 +167,14 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
 #endif
   const int kc = (c.kind == 1) ? 32 : 64;
   const size_t np = (size_t)g.ni * g.hth * g.htw;
-  size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0);
+  size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0) + (fused_up ? 128 : 0);
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
   if (lds_f < epi_f) lds_f = epi_f;
   const size_t lds = lds_f * sizeof(float);
   if (lds > 160 * 1024) return fail("conv: tile needs %zu B of LDS (> 160 KiB)", lds);
   const int groups = (c.B + g.ni - 1) / g.ni;
-  dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), c.kind == 2 ? 4u : 1u);
+  dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), (c.kind == 2 && !fused_up) ? 4u : 1u);
+  if (fused_up) return g.MT == 128 ? launch_conv_t<2, 4, 64>(a, grid, lds, s) : launch_conv_t<1, 4, 64>(a, grid, lds, s);
   (void)cin;
   if (c.kind == 0) return g.MT == 128 ? launch_conv_t<2, 0, 64>(a, grid, lds, s) : launch_conv_t<1, 0, 64>(a, grid, lds, s);
   if (c.kind == 2) return g.MT == 128 ? launch_conv_t<2, 2, 64>(a, grid, lds, s) : launch_conv_t<1, 2, 64>(a, grid, lds, s);

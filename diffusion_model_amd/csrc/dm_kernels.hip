@@ -27,6 +27,8 @@ __device__ __forceinline__ float dm_silu(float v) {
 // Implicit-GEMM convolution on fp32 MFMA.
 //   KIND 0: Conv2d 3x3 s1 p1      KIND 1: Conv2d 4x4 s2 p1      KIND 2: ConvTranspose2d 4x4 s2 p1
 //   KIND 3: Conv2d 1x1 (attention qkv / proj; optional residual add)
+//   KIND 4: ConvTranspose2d 4x4 s2 p1 with all four output parities computed from ONE staged
+//           tile (Cin == KC only): the input is read and transformed once instead of four times
 // GEMM view: M = output pixels (tile of MT = 64*MB pixels per workgroup), N = 64 output
 // channels per workgroup (blockIdx.y), K = taps x input channels, walked as
 // [channel chunk of KC][tap][8 channels].
@@ -80,12 +82,163 @@ struct ConvArgs {
 #define DM_STAMP(k) do {} while (0)
 #endif
 
+// Epilogue of conv_mfma_kernel for one set of accumulators: + bias; GroupNorm partial statistics;
+// NHWC store.  otile != null: the accumulators go through LDS ([MT][68], may overlay the input
+// tile — the caller has synchronised) and leave as coalesced float4 rows; otile == null (KIND 4,
+// the input tile must survive): straight from the registers, 128 B per half-wave.
+// scratch: >= 128 floats of LDS for the reductions.
+template <int MB, int KIND>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[MB], float* scratch, float* otile,
+                                              int par, int py, int px, int img0, int tin, int y0, int x0,
+                                              int wm, int wn, int lane, int h, int tid, int wave) {
+  constexpr int MT = 64 * MB;
+  constexpr bool UP = (KIND == 2 || KIND == 4);
+  const int th = 1 << p.th_log, tw = 1 << p.tw_log;
+  const int lc = wn * 32 + (lane & 31);  // column inside this workgroup's 64 output channels
+  const float bv = p.bias[blockIdx.y * 64 + lc];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mb][r] += bv;
+  const int OW = (KIND == 1) ? (p.W >> 1) : UP ? (p.W << 1) : p.W;
+  const int OH = (KIND == 1) ? (p.H >> 1) : UP ? (p.H << 1) : p.H;
+  constexpr int ORS = 68;                 // output staging row stride (floats)
+  float* sred = scratch;                  // [4 waves][NSW][4]
+  float* s_mu = sred + 64;                // [<= 64]
+
+  if (otile) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * (32 * MB) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        otile[m * ORS + lc] = acc[mb][r];
+      }
+  } else {
+    // (opaque copy: keeps LICM from hoisting the 32 store addresses out of the caller's K loop,
+    // where they would stay live in 64 registers and spill)
+    int hq = h;
+    asm volatile("" : "+v"(hq));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = wm * (32 * MB) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hq;
+        const int x = x0 + (m & (tw - 1));
+        const int y = y0 + ((m >> p.tw_log) & (th - 1));
+        const int n = img0 + (m >> (p.tw_log + p.th_log));
+        if (n < p.B) {
+          const int oy = UP ? 2 * y + py : y, ox = UP ? 2 * x + px : x;
+          p.y[(((size_t)n * OH + oy) * OW + ox) * p.Cout + blockIdx.y * 64 + lc] = acc[mb][r];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one address at a time: this runs with the K loop's registers live
+      }
+  }
+
+  if (p.stats_out) {
+    // Two passes over the accumulator registers (mean, then M2 about that mean), reduced with
+    // cross-lane shuffles and a few LDS words in a fixed order: the result depends neither on
+    // the batch size nor on dispatch order.  A 16-row segment never straddles two images.
+    constexpr int NSW = MB * 2;                          // 16-row segments per wave
+    const int G = p.Cout / DM_GROUPS;                    // channels per group: 8, 16, 32 or 64
+    const int GL = G < 32 ? G : 32;                      // lanes of one group inside a wave
+    const int gpt = 64 / G;                              // groups in this 64-channel tile
+    const int rows_img = (p.ni > 1) ? (th * tw) : MT;    // tile rows that belong to one image
+    const bool perseg = rows_img < 32 * MB;              // (then rows_img == 16: one image per segment)
+    const int nimg_t = MT / rows_img;
+    const int gg = (lane & 31) / GL;
+    float val[NSW];
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          float mu = 0.f;
+          if (pass == 1) {
+            const int i = perseg ? (wm * MB + mb) * 2 + sg : (wm * 32 * MB) / rows_img;
+            mu = s_mu[i * gpt + lc / G];
+          }
+          float sm = 0.f;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const float d = acc[mb][sg * 8 + r] - mu;
+            sm += (pass == 0) ? d : d * d;
+          }
+          val[mb * 2 + sg] = sm;
+        }
+      if (!perseg) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSW; ++k) t += val[k];
+        val[0] = t;
+      }
+#pragma unroll
+      for (int k = 0; k < NSW; ++k) {
+        if (k == 0 || perseg) {
+          float v = val[k];
+          v += __shfl_xor(v, 32, 64);
+          for (int o = 1; o < GL; o <<= 1) v += __shfl_xor(v, o, 64);
+          if (h == 0 && ((lane & 31) % GL) == 0) sred[(wave * NSW + k) * 4 + gg] = v;
+        }
+      }
+      __syncthreads();
+      if (tid < nimg_t * gpt) {
+        const int i = tid / gpt, g = tid - i * gpt;
+        float sm = 0.f;
+        // waves (wm) and slots (k) that cover image i; wn / gg that cover group g
+        const int wm0 = perseg ? i / NSW : (i * rows_img) / (32 * MB);
+        const int nwm = perseg ? 1 : (rows_img / (32 * MB));
+        const int k = perseg ? i % NSW : 0;
+        const int wn0 = (g * G) >> 5, nwn = (G == 64) ? 2 : 1, g2 = ((g * G) & 31) / GL;
+        for (int a = 0; a < nwm; ++a)
+          for (int b = 0; b < nwn; ++b) sm += sred[(((wm0 + a) * 2 + wn0 + b) * NSW + k) * 4 + g2];
+        if (pass == 0) {
+          s_mu[tid] = sm / (float)(rows_img * G);
+        } else {
+          const int n = img0 + i;
+          if (n < p.B) {
+            const int pidx = (UP ? par * p.tiles_per_img : 0) + tin;
+            float* so = p.stats_out + (((size_t)n * p.pout + pidx) * DM_GROUPS + blockIdx.y * gpt + g) * 2;
+            so[0] = s_mu[tid];
+            so[1] = sm;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else if (otile) {
+    __syncthreads();
+  }
+
+
+  // coalesced NHWC store: one pixel's 64 channels are 256 contiguous bytes
+  if (otile)
+  for (int idx = tid; idx < MT * 16; idx += 256) {
+    const int m = idx >> 4, c4 = idx & 15;
+    const int x = x0 + (m & (tw - 1));
+    const int y = y0 + ((m >> p.tw_log) & (th - 1));
+    const int n = img0 + (m >> (p.tw_log + p.th_log));
+    if (n < p.B) {
+      const int oy = UP ? 2 * y + py : y;
+      const int ox = UP ? 2 * x + px : x;
+      float4 v = *reinterpret_cast<const float4*>(otile + m * ORS + c4 * 4);
+      const size_t o = (((size_t)n * OH + oy) * OW + ox) * p.Cout + blockIdx.y * 64 + c4 * 4;
+      if (p.res) {
+        const float4 r = *reinterpret_cast<const float4*>(p.res + o);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4*>(p.y + o) = v;
+    }
+  }
+}
+
 template <int MB, int KIND, int KC>
 __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   constexpr int MT = 64 * MB;
   constexpr int RS = KC + 4;  // LDS row stride (floats): 16-B skew between consecutive pixels
   constexpr int S = (KIND == 1) ? 2 : 1;
-  constexpr int NTY = (KIND == 0) ? 3 : (KIND == 1) ? 4 : (KIND == 2) ? 2 : 1;
+  constexpr int NTY = (KIND == 0) ? 3 : (KIND == 1) ? 4 : (KIND == 2 || KIND == 4) ? 2 : 1;
+  constexpr int NTOT = (KIND == 4) ? 16 : NTY * NTY;  // taps walked by the K loop (4 parities x 4)
   constexpr int NT = NTY * NTY;
   constexpr int NJ = KC / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -102,8 +255,8 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int h = lane >> 5;
   const int Cin = p.C1 + p.C2;
-  const int par = (KIND == 2) ? blockIdx.z : 0;
-  const int py = par >> 1, px = par & 1;
+  int par = (KIND == 2) ? blockIdx.z : 0;  // KIND 4: advances inside the K loop
+  int py = par >> 1, px = par & 1;
   const int th = 1 << p.th_log, tw = 1 << p.tw_log;
 
   // ---- tile decode
@@ -112,8 +265,8 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   const int tin = t % p.tiles_per_img;
   const int y0 = (tin / p.tiles_x) << p.th_log;
   const int x0 = (tin % p.tiles_x) << p.tw_log;
-  const int hy0 = (KIND == 0) ? y0 - 1 : (KIND == 1) ? 2 * y0 - 1 : (KIND == 2) ? y0 - 1 + py : y0;
-  const int hx0 = (KIND == 0) ? x0 - 1 : (KIND == 1) ? 2 * x0 - 1 : (KIND == 2) ? x0 - 1 + px : x0;
+  const int hy0 = (KIND == 0 || KIND == 4) ? y0 - 1 : (KIND == 1) ? 2 * y0 - 1 : (KIND == 2) ? y0 - 1 + py : y0;
+  const int hx0 = (KIND == 0 || KIND == 4) ? x0 - 1 : (KIND == 1) ? 2 * x0 - 1 : (KIND == 2) ? x0 - 1 + px : x0;
   const int hth = p.hth, htw = p.htw;
   const int NP = p.ni * hth * htw;
 
@@ -257,13 +410,19 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) a0[mb] = *reinterpret_cast<const float4*>(tile + abase[mb]);
     int ty = 0, tx = 0;
-    for (int tap = 0; tap < NT; ++tap) {
-      const int tapoff = (ty * htw + tx) * RS;
+#pragma unroll 1
+    for (int tap = 0; tap < NTOT; ++tap) {
+      // KIND 4: tap = parity*4 + (ty*2+tx); parity (py,px) reads halo rows py+ty, columns px+tx
+      const int tapoff = (KIND == 4) ? (((tap >> 3) + ((tap >> 1) & 1)) * htw + ((tap >> 2) & 1) + (tap & 1)) * RS
+                                     : (ty * htw + tx) * RS;
       // next tap (clamped at the end: the extra prefetch re-reads valid data and is unused)
       int ntx = tx + 1, nty = ty;
       if (ntx == NTY) { ntx = 0; ++nty; }
-      const bool last = tap + 1 == NT;
-      const int ntapoff = last ? tapoff : (nty * htw + ntx) * RS;
+      const bool last = tap + 1 == NTOT;
+      const int nt = tap + 1;
+      const int ntapoff = last ? tapoff
+                        : (KIND == 4) ? (((nt >> 3) + ((nt >> 1) & 1)) * htw + ((nt >> 2) & 1) + (nt & 1)) * RS
+                                      : (nty * htw + ntx) * RS;
       const float* wnext = wbase + (size_t)(last ? tap : tap + 1) * tapstride;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -285,126 +444,24 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       tx = ntx; ty = nty;
+      if (KIND == 4 && (tap & 3) == 3) {
+        // one output parity is complete: store it (registers -> HBM; the input tile stays in
+        // LDS for the next parity), emit its statistics partial, restart the accumulators
+        par = tap >> 2; py = par >> 1; px = par & 1;
+        conv_epilogue<MB, KIND>(p, acc, tile + NP * RS, nullptr, par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+      }
     }
   }
 
   DM_STAMP(2);
   __builtin_amdgcn_s_setprio(2);
-  // ---- epilogue: + bias; GroupNorm partial statistics; NHWC store through LDS
-  const int lc = wn * 32 + (lane & 31);  // column inside this workgroup's 64 output channels
-  const float bv = p.bias[blockIdx.y * 64 + lc];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mb][r] += bv;
-  const int OW = (KIND == 1) ? (p.W >> 1) : (KIND == 2) ? (p.W << 1) : p.W;
-  const int OH = (KIND == 1) ? (p.H >> 1) : (KIND == 2) ? (p.H << 1) : p.H;
-  constexpr int ORS = 68;                 // output staging row stride (floats)
-  float* otile = smem;                    // [MT][ORS]
-  float* sred = smem + MT * ORS;          // [4 waves][NSW][4]
-  float* s_mu = sred + 64;                // [<= 64]
-
-  __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = wm * (32 * MB) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      otile[m * ORS + lc] = acc[mb][r];
-    }
-
-  if (p.stats_out) {
-    // Two passes over the accumulator registers (mean, then M2 about that mean), reduced with
-    // cross-lane shuffles and a few LDS words in a fixed order: the result depends neither on
-    // the batch size nor on dispatch order.  A 16-row segment never straddles two images.
-    constexpr int NSW = MB * 2;                          // 16-row segments per wave
-    const int G = p.Cout / DM_GROUPS;                    // channels per group: 8, 16, 32 or 64
-    const int GL = G < 32 ? G : 32;                      // lanes of one group inside a wave
-    const int gpt = 64 / G;                              // groups in this 64-channel tile
-    const int rows_img = (p.ni > 1) ? (th * tw) : MT;    // tile rows that belong to one image
-    const bool perseg = rows_img < 32 * MB;              // (then rows_img == 16: one image per segment)
-    const int nimg_t = MT / rows_img;
-    const int gg = (lane & 31) / GL;
-    float val[NSW];
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int sg = 0; sg < 2; ++sg) {
-          float mu = 0.f;
-          if (pass == 1) {
-            const int i = perseg ? (wm * MB + mb) * 2 + sg : (wm * 32 * MB) / rows_img;
-            mu = s_mu[i * gpt + lc / G];
-          }
-          float sm = 0.f;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            const float d = acc[mb][sg * 8 + r] - mu;
-            sm += (pass == 0) ? d : d * d;
-          }
-          val[mb * 2 + sg] = sm;
-        }
-      if (!perseg) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < NSW; ++k) t += val[k];
-        val[0] = t;
-      }
-#pragma unroll
-      for (int k = 0; k < NSW; ++k) {
-        if (k == 0 || perseg) {
-          float v = val[k];
-          v += __shfl_xor(v, 32, 64);
-          for (int o = 1; o < GL; o <<= 1) v += __shfl_xor(v, o, 64);
-          if (h == 0 && ((lane & 31) % GL) == 0) sred[(wave * NSW + k) * 4 + gg] = v;
-        }
-      }
-      __syncthreads();
-      if (tid < nimg_t * gpt) {
-        const int i = tid / gpt, g = tid - i * gpt;
-        float sm = 0.f;
-        // waves (wm) and slots (k) that cover image i; wn / gg that cover group g
-        const int wm0 = perseg ? i / NSW : (i * rows_img) / (32 * MB);
-        const int nwm = perseg ? 1 : (rows_img / (32 * MB));
-        const int k = perseg ? i % NSW : 0;
-        const int wn0 = (g * G) >> 5, nwn = (G == 64) ? 2 : 1, g2 = ((g * G) & 31) / GL;
-        for (int a = 0; a < nwm; ++a)
-          for (int b = 0; b < nwn; ++b) sm += sred[(((wm0 + a) * 2 + wn0 + b) * NSW + k) * 4 + g2];
-        if (pass == 0) {
-          s_mu[tid] = sm / (float)(rows_img * G);
-        } else {
-          const int n = img0 + i;
-          if (n < p.B) {
-            const int pidx = ((KIND == 2) ? par * p.tiles_per_img : 0) + tin;
-            float* so = p.stats_out + (((size_t)n * p.pout + pidx) * DM_GROUPS + blockIdx.y * gpt + g) * 2;
-            so[0] = s_mu[tid];
-            so[1] = sm;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  } else {
-    __syncthreads();
-  }
-
-  // coalesced NHWC store: one pixel's 64 channels are 256 contiguous bytes
-  for (int idx = tid; idx < MT * 16; idx += 256) {
-    const int m = idx >> 4, c4 = idx & 15;
-    const int x = x0 + (m & (tw - 1));
-    const int y = y0 + ((m >> p.tw_log) & (th - 1));
-    const int n = img0 + (m >> (p.tw_log + p.th_log));
-    if (n < p.B) {
-      const int oy = (KIND == 2) ? 2 * y + py : y;
-      const int ox = (KIND == 2) ? 2 * x + px : x;
-      float4 v = *reinterpret_cast<const float4*>(otile + m * ORS + c4 * 4);
-      const size_t o = (((size_t)n * OH + oy) * OW + ox) * p.Cout + blockIdx.y * 64 + c4 * 4;
-      if (p.res) {
-        const float4 r = *reinterpret_cast<const float4*>(p.res + o);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-      }
-      *reinterpret_cast<float4*>(p.y + o) = v;
-    }
+  if (KIND != 4) {
+    __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
+    conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
   }
   DM_STAMP(3);
 }
