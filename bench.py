@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per pass")
     ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = BASELINE configs[3] arithmetic (not the default metric)")
+    ap.add_argument("--cfg", action="store_true", help="class-conditional + classifier-free guidance (doubled batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -63,7 +66,7 @@ def main():
 
     B, n = args.batch, args.ddim_steps
     d.set_seed(42)
-    model = d.UNetMini(image_size=32).eval()       # random-init weights of the reference architecture
+    model = d.UNetMini(image_size=32, precision=args.precision).eval()  # random-init weights, reference architecture
     sched = d.DDPMScheduler()
     smp = d.DDIMSampler(sched, num_inference_steps=n, eta=0.0)
     # synthetic x_T: the full [world*B] draw, each rank takes its row slice
@@ -72,6 +75,12 @@ def main():
     x_T_full = torch.randn((world * B, 1, 32, 32), generator=g).to(dev)  # same draw on every rank
     x_T = x_T_full[rank * B:(rank + 1) * B]
     fn = sampler_fn(smp, model)
+    if args.cfg:  # build-defined guided sampling: labels arange % 10, null class 10, w = 3
+        cc = d.ClassConditioner(11, 128)
+        cond_full = cc(torch.arange(world * B) % 10)
+        null = cc(torch.tensor([10]))
+        fn = lambda x, nz: smp.sample_from(model, x, cond_emb=cond_full[rank * B:(rank + 1) * B], null_emb=null,
+                                           guidance_scale=3.0)
 
     def one_pass():
         # rank r samples rows [r*B, (r+1)*B); one RCCL all-gather of the finished samples
@@ -101,10 +110,11 @@ def main():
     res = {
         "metric": "sampled images/sec (DDIM-50, 32x32 MNIST UNet)", "value": value, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
         "config": {"workload": f"DDIM-{n} eta=0, UNetMini(32x32, C=64) random-init seed 42, batch {B} per GPU, "
                                "x_T resident in HBM (BASELINE configs[1])",
-                   "images_per_gpu": B, "ddim_steps": n, "parallelism": f"dp{world} (batch-sharded, final all-gather)"},
+                   "images_per_gpu": B, "ddim_steps": n, "guidance": bool(args.cfg), "parallelism": f"dp{world} (batch-sharded, final all-gather)"},
         "achieved_tflops_whole_path": value * n * FLOP_PER_IMAGE_STEP / 1e12,
         "frac_fp32_mfma_peak_whole_path": value * n * FLOP_PER_IMAGE_STEP / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
     }
@@ -136,16 +146,24 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
         if os.path.exists(tpath) and B == 1024:
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
-        res["roofline"] = {"kernel": "conv_mfma_kernel<2,0,64> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)",
-                           "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                           "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, B=1024)",
-                           "algorithmic_bytes_per_launch": by[k] / counts[k],
-                           "avg_launch_us": 1e3 * ms[k] / counts[k], "flop_per_launch": fl[k] / counts[k],
-                           "share_of_denoiser_time": ms[k] / tot_ms}
+        if args.precision == "bf16":
+            # at 16x the MFMA rate the bf16 conv kernel is bound by its activation traffic
+            gbps = by[k] / (ms[k] * 1e-3) / 1e9
+            res["roofline"] = {"kernel": "conv_bf16_kernel<2,0> (3x3 implicit GEMM, v_mfma_f32_32x32x16_bf16)",
+                               "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                               "traffic": None, "avg_launch_us": 1e3 * ms[k] / counts[k],
+                               "algorithmic_bytes_per_launch": by[k] / counts[k], "share_of_denoiser_time": ms[k] / tot_ms}
+        else:
+          res["roofline"] = {"kernel": "conv_mfma_kernel<2,0,64> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                             "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, B=1024)",
+                             "algorithmic_bytes_per_launch": by[k] / counts[k],
+                             "avg_launch_us": 1e3 * ms[k] / counts[k], "flop_per_launch": fl[k] / counts[k],
+                             "share_of_denoiser_time": ms[k] / tot_ms}
         res["kernels"] = per
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.cfg:
         from oracle import unet_oracle as O
         sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
         cb = 128

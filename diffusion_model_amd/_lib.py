@@ -20,6 +20,7 @@ _SIGS = {
     "dm_unet_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i]),
     "dm_unet_create_ex": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
     "dm_unet_num_params": (_i, [_vp]),
+    "dm_unet_set_precision": (_i, [_vp, _i]),
     "dm_unet_destroy": (None, [_vp]),
     "dm_unet_packed_floats": (_sz, [_vp]),
     "dm_unet_pack_weights": (_i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _vp]),

@@ -3,6 +3,7 @@
 // sequence (diffusion/model.py:120-151), the sampling loop and its hipGraph capture
 // (diffusion/sampler.py:45-76,136-172).  No torch types; plain pointers and sizes.
 #include "dm_kernels.hip"
+#include "dm_kernels_bf16.hip"
 #include "../../include/dm_sampler.h"
 
 #include <hip/hip_runtime.h>
@@ -112,6 +113,7 @@ struct ConvCall {
   float* y; float* stats_out;
   int B, H, W;
   const float* res; int no_silu;
+  int bf16;  // activations and packed weights are bf16 (conv_bf16_kernel)
 };
 
 template <int MB, int KIND, int KC>
@@ -135,6 +137,25 @@ int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   return 0;
 }
 
+template <int MB, int KIND>
+int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MB, KIND>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const int cls = KIND == 0 ? (MB == 2 ? DM_K_CONV3_128 : DM_K_CONV3_64) : KIND == 1 ? DM_K_DOWN : (MB == 2 ? DM_K_UP_128 : DM_K_UP_64);
+  const double opix = (double)a.B * a.Hb * a.Wb * (KIND == 2 ? 4 : 1);
+  const double ipix = (double)a.B * a.H * a.W;
+  const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : 4;
+  const int cin = a.C1 + a.C2;
+  ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 2.0 * (ipix * cin + opix * a.Cout + taps * (KIND == 2 ? 4 : 1) * cin * a.Cout));
+  hipLaunchKernelGGL((conv_bf16_kernel<MB, KIND>), grid, dim3(256), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int launch_conv(const ConvCall& c, hipStream_t s) {
   const int cin = c.c1 + c.c2;
   if (c.kind < 0 || c.kind > 3) return fail("conv: unknown kind %d", c.kind);
@@ -147,7 +168,8 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   if (c.B <= 0) return fail("conv: empty batch");
   ConvGeo g = conv_geo(c.kind, c.H, c.W, c.cout);
   // transposed conv with a single K chunk: all four output parities from one staged tile
-  const bool fused_up = c.kind == 2 && cin == 64;
+  if (c.bf16 && (c.kind == 3 || c.res)) return fail("conv: the bf16 path has no 1x1 / residual variant");
+  const bool fused_up = c.kind == 2 && cin == 64 && !c.bf16;
   if (fused_up) { g.hth += 1; g.htw += 1; }
   ConvArgs a;
   memset(&a, 0, sizeof a);
@@ -170,10 +192,20 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0) + (fused_up ? 128 : 0);
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
   if (lds_f < epi_f) lds_f = epi_f;
+  if (c.bf16) {
+    lds_f = (np * (64 + 8) + 1) / 2 + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0);
+    const size_t e2 = (size_t)g.MT * 36 + 128;
+    if (lds_f < e2) lds_f = e2;
+  }
   const size_t lds = lds_f * sizeof(float);
   if (lds > 160 * 1024) return fail("conv: tile needs %zu B of LDS (> 160 KiB)", lds);
   const int groups = (c.B + g.ni - 1) / g.ni;
   dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), (c.kind == 2 && !fused_up) ? 4u : 1u);
+  if (c.bf16) {
+    if (c.kind == 0) return g.MT == 128 ? launch_conv_bf16_t<2, 0>(a, grid, lds, s) : launch_conv_bf16_t<1, 0>(a, grid, lds, s);
+    if (c.kind == 2) return g.MT == 128 ? launch_conv_bf16_t<2, 2>(a, grid, lds, s) : launch_conv_bf16_t<1, 2>(a, grid, lds, s);
+    return launch_conv_bf16_t<1, 1>(a, grid, lds, s);
+  }
   if (fused_up) return g.MT == 128 ? launch_conv_t<2, 4, 64>(a, grid, lds, s) : launch_conv_t<1, 4, 64>(a, grid, lds, s);
   (void)cin;
   if (c.kind == 0) return g.MT == 128 ? launch_conv_t<2, 0, 64>(a, grid, lds, s) : launch_conv_t<1, 0, 64>(a, grid, lds, s);
@@ -187,9 +219,16 @@ size_t conv_packed_floats(int kind, int cin, int cout) {
   return (size_t)taps * cin * cout;
 }
 
-int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream_t s) {
-  if (cin % 8 || cout % 32) return fail("pack_conv: cin %% 8 / cout %% 32");
+int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream_t s, int bf16 = 0) {
+  if (cin % 16 || cout % 32) return fail("pack_conv: cin %% 16 / cout %% 32");
   const size_t total = conv_packed_floats(kind, cin, cout);
+  if (bf16) {
+    if (kind == 3) return fail("pack_conv: no bf16 1x1 variant");
+    hipLaunchKernelGGL(pack_conv_weight_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind, w, cin, cout,
+                       reinterpret_cast<bf16_t*>(out), total);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind, w, cin, cout, out, total);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -212,6 +251,7 @@ struct AttnOff { size_t ng, nb, qkv, qkvb, proj, projb; };
 
 struct dm_unet {
   int Cin, Cout, C, E;
+  int bf16;            // 1: bf16 activations + conv weights (fp32 accumulate / statistics)
   int attn;            // build-defined attention blocks at 1/4 resolution (after down2 and up1)
   AttnOff att[2];
   size_t o_freqs, o_tm1w, o_tm1b, o_tm2w, o_tm2b, o_initw, o_initb;
@@ -347,14 +387,18 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     unsigned blocks = (unsigned)((total + 255) / 256);
     if (blocks > 65536u * 4) blocks = 65536u * 4;
     ProfScope ps(DM_K_INIT, s, 2.0 * B * H * W * C * 9 * m->Cin, 4.0 * B * H * W * (m->Cin + C));
-    hipLaunchKernelGGL(init_conv_kernel, dim3(blocks), dim3(256), lds, s, x, P + m->o_initw, P + m->o_initb, w.A0, B, m->Cin, H, W, C);
+    if (m->bf16)
+      hipLaunchKernelGGL(init_conv_bf16_kernel, dim3(blocks), dim3(256), lds, s, x, P + m->o_initw, P + m->o_initb,
+                         reinterpret_cast<bf16_t*>(w.A0), B, m->Cin, H, W, C);
+    else
+      hipLaunchKernelGGL(init_conv_kernel, dim3(blocks), dim3(256), lds, s, x, P + m->o_initw, P + m->o_initb, w.A0, B, m->Cin, H, W, C);
     HIP_TRY(hipGetLastError());
   }
   ConvCall c;
   auto base = [&](int kind, const float* x1, int c1, const float* x2, int c2, size_t wp, size_t bias, float* y, float* so, int h, int ww) {
     memset(&c, 0, sizeof c);
     c.kind = kind; c.x1 = x1; c.c1 = c1; c.x2 = x2; c.c2 = c2; c.wp = P + wp; c.bias = P + bias; c.cout = C;
-    c.y = y; c.stats_out = so; c.B = B; c.H = h; c.W = ww;
+    c.y = y; c.stats_out = so; c.B = B; c.H = h; c.W = ww; c.bf16 = m->bf16;
   };
   auto with_tf = [&](const float* si, int kind_prod, int hp, int wp_, size_t g, size_t b) {
     const ConvGeo pg = conv_geo(kind_prod, hp, wp_, C);
@@ -399,8 +443,13 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     const ConvGeo pg = conv_geo(2, H / 2, W / 2, C);
     const size_t lds = (size_t)(3 * C + m->Cout * C) * sizeof(float);
     ProfScope ps(DM_K_FINAL, s, 2.0 * B * H * W * C * m->Cout, 4.0 * B * H * W * (C + m->Cout));
-    hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)(B * (H * W / 64))), dim3(256), lds, s, w.A0, w.SA, pg.pout,
-                       pg.cnt_out, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H * W, C, m->Cout);
+    if (m->bf16)
+      hipLaunchKernelGGL(final_conv_bf16_kernel, dim3((unsigned)(B * (H * W / 64))), dim3(256), lds, s,
+                         reinterpret_cast<const bf16_t*>(w.A0), w.SA, pg.pout, pg.cnt_out, P + m->o_fg, P + m->o_fb,
+                         P + m->o_fw, P + m->o_fwb, eps, B, H * W, C, m->Cout);
+    else
+      hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)(B * (H * W / 64))), dim3(256), lds, s, w.A0, w.SA, pg.pout,
+                         pg.cnt_out, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H * W, C, m->Cout);
     HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -436,6 +485,15 @@ int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_c
   return dm_unet_create_ex(out, in_channels, out_channels, model_channels, time_emb_dim, 0);
 }
 
+int dm_unet_set_precision(dm_unet* m, int bf16) {
+  if (!m) return fail("dm_unet_set_precision: null handle");
+  if (bf16 && m->attn) return fail("the bf16 path does not cover the attention blocks");
+  m->bf16 = bf16 ? 1 : 0;
+  for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+  m->graphs.clear();
+  return 0;
+}
+
 int dm_unet_num_params(const dm_unet* m) { return m ? DM_UNET_NUM_PARAMS + (m->attn ? 12 : 0) : 0; }
 
 int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int model_channels, int time_emb_dim,
@@ -450,6 +508,7 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
   dm_unet* m = new dm_unet();
   m->Cin = in_channels; m->Cout = out_channels; m->C = model_channels; m->E = time_emb_dim;
   m->attn = attention ? 1 : 0;
+  m->bf16 = 0;
   const int C = m->C, E = m->E;
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
@@ -520,16 +579,16 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
     const bool up = k >= 3;
     const BlockOff& b = m->blk[k];
     if (copy(b.tmw, p[i++], (size_t)C * E) || copy(b.tmb, p[i++], C)) return 1;
-    if (pack_conv(0, p[i++], up ? 2 * C : C, C, packed + b.c1, s) || copy(b.c1b, p[i++], C)) return 1;
-    if (pack_conv(up ? 2 : 1, p[i++], C, C, packed + b.tr, s) || copy(b.trb, p[i++], C)) return 1;
-    if (pack_conv(0, p[i++], C, C, packed + b.c2, s) || copy(b.c2b, p[i++], C)) return 1;
+    if (pack_conv(0, p[i++], up ? 2 * C : C, C, packed + b.c1, s, m->bf16) || copy(b.c1b, p[i++], C)) return 1;
+    if (pack_conv(up ? 2 : 1, p[i++], C, C, packed + b.tr, s, m->bf16) || copy(b.trb, p[i++], C)) return 1;
+    if (pack_conv(0, p[i++], C, C, packed + b.c2, s, m->bf16) || copy(b.c2b, p[i++], C)) return 1;
     if (copy(b.g1, p[i++], C) || copy(b.b1, p[i++], C) || copy(b.g2, p[i++], C) || copy(b.b2, p[i++], C)) return 1;
     return 0;
   };
   for (int k = 0; k < 3; ++k) if (do_block(k)) return 1;
-  if (pack_conv(0, p[i++], C, C, packed + m->o_b0, s) || copy(m->o_b0b, p[i++], C) ||
+  if (pack_conv(0, p[i++], C, C, packed + m->o_b0, s, m->bf16) || copy(m->o_b0b, p[i++], C) ||
       copy(m->o_bg, p[i++], C) || copy(m->o_bb, p[i++], C) ||
-      pack_conv(0, p[i++], C, C, packed + m->o_b3, s) || copy(m->o_b3b, p[i++], C)) return 1;
+      pack_conv(0, p[i++], C, C, packed + m->o_b3, s, m->bf16) || copy(m->o_b3b, p[i++], C)) return 1;
   for (int k = 3; k < 6; ++k) if (do_block(k)) return 1;
   if (copy(m->o_fg, p[i++], C) || copy(m->o_fb, p[i++], C) ||
       copy(m->o_fw, p[i++], (size_t)m->Cout * C) || copy(m->o_fwb, p[i++], m->Cout)) return 1;

@@ -87,7 +87,11 @@ struct ConvArgs {
 // tile — the caller has synchronised) and leave as coalesced float4 rows; otile == null (KIND 4,
 // the input tile must survive): straight from the registers, 128 B per half-wave.
 // scratch: >= 128 floats of LDS for the reductions.
-template <int MB, int KIND>
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // RNE (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((unsigned)b << 16); }
+
+template <int MB, int KIND, bool BF = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[MB], float* scratch, float* otile,
                                               int par, int py, int px, int img0, int tin, int y0, int x0,
                                               int wm, int wn, int lane, int h, int tid, int wave) {
@@ -112,7 +116,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = wm * (32 * MB) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        otile[m * ORS + lc] = acc[mb][r];
+        if (BF) reinterpret_cast<bf16_t*>(otile)[m * 72 + lc] = f2bf(acc[mb][r]);  // [MT][64+8] bf16
+        else otile[m * ORS + lc] = acc[mb][r];
       }
   } else {
     // (opaque copy: keeps LICM from hoisting the 32 store addresses out of the caller's K loop,
@@ -212,6 +217,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 
 
   // coalesced NHWC store: one pixel's 64 channels are 256 contiguous bytes
+  if (BF) {  // bf16 activations: one pixel's 64 channels are 128 contiguous bytes
+    for (int idx = tid; idx < MT * 8; idx += 256) {
+      const int m = idx >> 3, c8 = idx & 7;
+      const int x = x0 + (m & (tw - 1));
+      const int y = y0 + ((m >> p.tw_log) & (th - 1));
+      const int n = img0 + (m >> (p.tw_log + p.th_log));
+      if (n < p.B) {
+        const int oy = UP ? 2 * y + py : y;
+        const int ox = UP ? 2 * x + px : x;
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(otile) + m * 72 + c8 * 8);
+        bf16_t* yb = reinterpret_cast<bf16_t*>(p.y);
+        *reinterpret_cast<uint4*>(yb + (((size_t)n * OH + oy) * OW + ox) * p.Cout + blockIdx.y * 64 + c8 * 8) = v;
+      }
+    }
+    return;
+  }
   if (otile)
   for (int idx = tid; idx < MT * 16; idx += 256) {
     const int m = idx >> 4, c4 = idx & 15;

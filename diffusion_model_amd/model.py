@@ -75,9 +75,14 @@ class UNetMini(nn.Module):
     ``timesteps`` is a 0-dim int64 tensor (sampling) or a [B] tensor (training style)."""
 
     def __init__(self, image_size=28, in_channels=1, out_channels=1, model_channels=64,
-                 time_emb_dim=128, attention=False):
+                 time_emb_dim=128, attention=False, precision="fp32"):
         super().__init__()
         self.attention = bool(attention)  # build-defined extension; False = the reference model
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"Unknown precision: {precision}")
+        # "bf16": bf16 activations / conv weights, fp32 accumulate (BASELINE configs[3]); the
+        # parameters themselves stay fp32 (state_dict unchanged)
+        self.precision = precision
         self.device = get_device()
         self.image_size = image_size
         self.in_channels = in_channels
@@ -131,6 +136,7 @@ class UNetMini(nn.Module):
             h = C.c_void_p()
             _lib.check(_lib.lib().dm_unet_create_ex(C.byref(h), self.in_channels, self.out_channels,
                                                     self.model_channels, self.time_emb_dim, int(self.attention)))
+            _lib.check(_lib.lib().dm_unet_set_precision(h, 1 if self.precision == "bf16" else 0))
             self._handle = h
         return self._handle
 

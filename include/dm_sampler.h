@@ -49,6 +49,11 @@ int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_c
 int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int model_channels,
                       int time_emb_dim, int attention);
 int dm_unet_num_params(const dm_unet* m);
+/* bf16 != 0: activations between kernels and the packed conv weights are bfloat16, MFMA is
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; GroupNorm statistics, the SiLU transform, the
+ * time embedding, eps and the sampler update stay fp32 (BASELINE configs[3]; north_star tolerance
+ * |eps - eps_fp32| <= 2e-2).  Call BEFORE dm_unet_pack_weights; drops cached graphs. */
+int dm_unet_set_precision(dm_unet* m, int bf16);
 void dm_unet_destroy(dm_unet* m);
 
 /* Size (in floats) of the packed weight blob for this geometry. */

@@ -264,3 +264,48 @@ def test_attention_unet_vs_oracle(size, cin, C):
     out = smp.sample_from(m, x).cpu()
     refs = O.sample(sdc, O.make_schedule(), x.shape, 4, 0.0, x_T=x)
     assert (out - refs).abs().max().item() <= 1e-3
+
+
+# ---------------------------------------------------------------- bf16 (BASELINE configs[3])
+BF16_EPS_TOL = 2e-2  # north_star: per-step eps max-abs <= 2e-2 in bf16
+
+
+def test_bf16_forward_and_ddim50(golden, sd):
+    m = d.UNetMini(image_size=32, precision="bf16").eval()
+    m.load_state_dict(sd)
+    x = golden["fwd_x"].to(DEV)
+    for t in (0, 500, 999):
+        eps = m(x, torch.tensor(t)).cpu()
+        assert (eps - golden[f"fwd_eps_t{t}"]).abs().max().item() <= BF16_EPS_TOL
+    assert (m(x, golden["fwd_tb"].to(DEV)).cpu() - golden["fwd_eps_tb"]).abs().max().item() <= BF16_EPS_TOL
+    # teacher-forced per-step eps along the reference's own DDIM-50 chain
+    sched = d.DDPMScheduler()
+    smp = d.DDIMSampler(sched, num_inference_steps=50, eta=0.0)
+    worst = 0.0
+    for i in range(50):
+        eps = m(golden["ddim50_xs"][i].to(DEV), sched.timesteps[i]).cpu()
+        worst = max(worst, (eps - golden["ddim50_es"][i]).abs().max().item())
+    assert worst <= BF16_EPS_TOL, worst
+    out = smp.sample_from(m, golden["ddim50_x_T"]).cpu()
+    ref = golden["ddim50_out"]
+    psnr = O.psnr(out, ref, float(ref.max() - ref.min()))
+    print("bf16 DDIM-50 worst eps err", worst, "PSNR", psnr.tolist())
+    assert psnr.min().item() >= 40.0, psnr
+    # batch independence holds in bf16 too
+    full = m(x, torch.tensor(321))
+    assert torch.equal(m(x[1:3].contiguous(), torch.tensor(321)), full[1:3])
+
+
+def test_bf16_cfg_sampling(golden, sd):
+    """BASELINE configs[3]: class-conditional + classifier-free guidance (doubled batch), bf16."""
+    cc, cd = _conditioner()
+    m = d.UNetMini(image_size=32, precision="bf16").eval()
+    m.load_state_dict(sd)
+    B, n, w = 4, 10, 3.0
+    torch.manual_seed(22)
+    x_T = torch.randn(B, 1, 32, 32)
+    lab = torch.tensor([0, 3, 6, 9])
+    smp = d.DDIMSampler(d.DDPMScheduler(), num_inference_steps=n, eta=0.0)
+    out = smp.sample_from(m, x_T, cond_emb=cc(lab), null_emb=cc(torch.tensor([10])), guidance_scale=w).cpu()
+    ref = O.cfg_sample(sd, cd, O.make_schedule(), x_T, lab, 10, w, n)
+    assert O.psnr(out, ref, float(ref.max() - ref.min())).min().item() >= 40.0
