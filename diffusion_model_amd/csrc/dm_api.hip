@@ -114,6 +114,7 @@ struct ConvCall {
   int B, H, W;
   const float* res; int no_silu;
   int bf16;  // activations and packed weights are bf16 (conv_bf16_kernel)
+  const float* init_x; const float* init_w; const float* init_b; int init_cin;  // folded init_conv
 };
 
 template <int MB, int KIND, int KC>
@@ -184,16 +185,19 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   a.mg_hth = (unsigned)((0x100000000ull + g.hth - 1) / g.hth);
   a.pout = g.pout;
   a.res = c.res; a.tf_silu = c.no_silu ? 0 : 1;
+  a.init_x = c.init_x; a.init_w = c.init_w; a.init_b = c.init_b; a.init_cin = c.init_cin;
+  if (c.init_x && (c.kind != 0 || c.stats_in || c.c2)) return fail("conv: folded init_conv needs a plain 3x3 conv");
+  const size_t init_f = c.init_x ? (size_t)g.ni * c.init_cin * (g.hth + 2) * (g.htw + 2) + 4 + (size_t)c.init_cin * 9 * 64 + 64 + 8 : 0;
 #ifdef DM_STAMPS
   a.stamps = g_stamps;
 #endif
   const int kc = (c.kind == 1) ? 32 : 64;
   const size_t np = (size_t)g.ni * g.hth * g.htw;
-  size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0) + (fused_up ? 128 : 0);
+  size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0) + (fused_up ? 128 : 0) + init_f;
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
   if (lds_f < epi_f) lds_f = epi_f;
   if (c.bf16) {
-    lds_f = (np * (64 + 8) + 1) / 2 + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0);
+    lds_f = (np * (64 + 8) + 1) / 2 + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0) + init_f;
     const size_t e2 = (size_t)g.MT * 36 + 128;
     if (lds_f < e2) lds_f = e2;
   }
@@ -381,7 +385,9 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
               int heads_img_stride, int heads_step_stride, const int* step_ptr, int step_off,
               const Workspace& w, int B, int H, int W, hipStream_t s) {
   const int C = m->C;
-  {  // init_conv (model.py:135)
+  // init_conv (model.py:135) is folded into down1.conv1's staging (no kernel, no HBM round trip)
+  const bool fold_init = true;
+  if (!fold_init) {
     const size_t lds = (size_t)m->Cin * 9 * C * sizeof(float);
     const size_t total = (size_t)B * H * W * (C / 4);
     unsigned blocks = (unsigned)((total + 255) / 256);
@@ -408,6 +414,9 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   auto block = [&](int k, const float* in1, const float* in2, int h, int ww, bool up, float* out, float* out_stats) -> int {
     const BlockOff& o = m->blk[k];
     base(0, in1, C, in2, in2 ? C : 0, o.c1, o.c1b, w.T1, w.SA, h, ww);
+    if (k == 0 && fold_init) {
+      c.init_x = x; c.init_w = P + m->o_initw; c.init_b = P + m->o_initb; c.init_cin = m->Cin;
+    }
     if (launch_conv(c, s)) return 1;
     base(0, w.T1, C, nullptr, 0, o.c2, o.c2b, w.T2, w.SB, h, ww);
     with_tf(w.SA, 0, h, ww, o.g1, o.b1);

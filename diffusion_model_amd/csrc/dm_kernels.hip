@@ -71,6 +71,12 @@ struct ConvArgs {
   int hth, htw;           // halo tile dims (input pixels)
   unsigned mg_htw, mg_hth; // ceil(2^32/d) magic dividers
   int pout;               // output partials per image
+  // init_conv folded into this conv's staging (KIND 0, down1.conv1): when init_x != null the input
+  // tile is COMPUTED from the NCHW image (3x3 conv, init_cin -> C1 channels) instead of loaded
+  const float* init_x;    // [B, init_cin, H, W]
+  const float* init_w;    // [C1, init_cin, 3, 3]
+  const float* init_b;    // [C1]
+  int init_cin;
 #ifdef DM_STAMPS
   unsigned long long* stamps;  // diagnostic build only: [grid][4] s_memtime stamps
 #endif
@@ -88,6 +94,74 @@ struct ConvArgs {
 // the input tile must survive): straight from the registers, 128 B per half-wave.
 // scratch: >= 128 floats of LDS for the reductions.
 typedef unsigned short bf16_t;  // raw bfloat16 bits
+__device__ __forceinline__ bf16_t f2bf(float f);
+
+// Stage the input tile of down1.conv1 by evaluating init_conv (model.py:90,135) on the fly:
+// tile[pixel][c] = bias[c] + sum_{ci,ky,kx} x[n][ci][iy+ky-1][ix+kx-1] * w[c][ci][ky][kx] for halo
+// pixels inside the image, exactly 0 outside (the 3x3 conv's own zero padding).  Same summation
+// order as init_conv_kernel, so the result is bit-identical to the two-kernel form while the
+// 256 KiB/image write + re-read of the init activation disappears.  aux: LDS scratch for the
+// image patch (halo + 1) and the 64 output channels' weights.  Caller barriers afterwards.
+template <bool BF, int RSX>
+__device__ __forceinline__ void stage_init_tile(const ConvArgs& p, void* tile_v, float* aux, int chan0, int img0,
+                                                int hy0, int hx0, int hth, int htw, int tid) {
+  const int Ci = p.init_cin;
+  const int ph = hth + 2, pw = htw + 2;
+  float* xs = aux;                                   // [ni][Ci][ph][pw]
+  float* wl = aux + ((p.ni * Ci * ph * pw + 3) & ~3);  // [Ci*9][64]
+  float* bl = wl + Ci * 9 * 64;                      // [64]
+  for (int idx = tid; idx < p.ni * Ci * ph * pw; idx += 256) {
+    const int xx = idx % pw;
+    int r = idx / pw;
+    const int yy = r % ph;
+    r /= ph;
+    const int ci = r % Ci, i = r / Ci;
+    const int iy = hy0 - 1 + yy, ix = hx0 - 1 + xx, n = img0 + i;
+    float v = 0.f;
+    if (n < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+      v = p.init_x[(((size_t)n * Ci + ci) * p.H + iy) * p.W + ix];
+    xs[idx] = v;
+  }
+  for (int idx = tid; idx < Ci * 9 * 64; idx += 256) {
+    const int c = idx & 63, k = idx >> 6;
+    wl[idx] = p.init_w[(size_t)(chan0 + c) * Ci * 9 + k];
+  }
+  if (tid < 64) bl[tid] = p.init_b[chan0 + tid];
+  __syncthreads();
+  const int NP = p.ni * hth * htw;
+  for (int idx = tid; idx < NP * 16; idx += 256) {
+    const int pix = idx >> 4, c4 = idx & 15;
+    const int r = __umulhi((unsigned)pix, p.mg_htw);
+    const int hx = pix - r * htw;
+    const int i = __umulhi((unsigned)r, p.mg_hth);
+    const int hy = r - i * hth;
+    const int iy = hy0 + hy, ix = hx0 + hx, n = img0 + i;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+      a = *reinterpret_cast<const float4*>(bl + c4 * 4);
+      for (int ci = 0; ci < Ci; ++ci) {
+        const float* xp = xs + ((i * Ci + ci) * ph + hy) * pw + hx;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float xv = xp[ky * pw + kx];
+            const float4 wv = *reinterpret_cast<const float4*>(wl + (ci * 9 + ky * 3 + kx) * 64 + c4 * 4);
+            a.x += xv * wv.x; a.y += xv * wv.y; a.z += xv * wv.z; a.w += xv * wv.w;
+          }
+      }
+    }
+    if (BF) {
+      uint2 o;
+      o.x = (unsigned)f2bf(a.x) | ((unsigned)f2bf(a.y) << 16);
+      o.y = (unsigned)f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(tile_v) + pix * RSX + c4 * 4) = o;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(tile_v) + pix * RSX + c4 * 4) = a;
+    }
+  }
+}
+
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // RNE (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((unsigned)b << 16); }
 
@@ -334,6 +408,9 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
     }  // previous chunk's LDS reads are done
     // ---- stage: global -> (transform) -> LDS, U loads in flight per thread (HBM latency
     // is ~2 us under load; one load at a time would make this phase latency-bound)
+    if (KIND == 0 && p.init_x) {
+      stage_init_tile<false, RS>(p, tile, tile + NP * RS, cg0, img0, hy0, hx0, hth, htw, tid);
+    } else
     for (int base = 0; base < items; base += 256 * U) {  // uniform trip count (barrier inside)
       float4 v[U];
       int meta[U];  // (LDS float offset) | (table offset + 1) << 16; table part 0 = no transform

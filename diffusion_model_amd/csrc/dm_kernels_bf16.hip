@@ -78,6 +78,9 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const ConvArgs p) {
       __builtin_amdgcn_s_setprio(2);
       __syncthreads();
     }
+    if (KIND == 0 && p.init_x) {
+      stage_init_tile<true, RSB>(p, tile, reinterpret_cast<float*>(tile + ((NP * RSB + 7) & ~7)), cg0, img0, hy0, hx0, hth, htw, tid);
+    } else
     for (int base = 0; base < items; base += 256 * U) {
       uint4 v[U];
       int meta[U];
