@@ -185,6 +185,14 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   a.mg_hth = (unsigned)((0x100000000ull + g.hth - 1) / g.hth);
   a.pout = g.pout;
   a.res = c.res; a.tf_silu = c.no_silu ? 0 : 1;
+  if (!is_pow2(c.c1) || (c.c2 && !is_pow2(c.c2)))
+    return fail("conv: input channel counts must be powers of two (got %d+%d)", c.c1, c.c2);
+  a.h_log = ilog2(c.H); a.w_log = ilog2(c.W); a.c1_log = ilog2(c.c1); a.c2_log = c.c2 ? ilog2(c.c2) : 0;
+  a.cout_log = is_pow2(c.cout) ? ilog2(c.cout) : -1;
+  {
+    const int ppp = (c.bf16 || c.kind == 1) ? 32 : 16;  // 256 threads / (16-byte loads per pixel per chunk)
+    a.ppp_q = ppp / g.htw; a.ppp_r = ppp % g.htw;
+  }
   a.init_x = c.init_x; a.init_w = c.init_w; a.init_b = c.init_b; a.init_cin = c.init_cin;
   if (c.init_x && (c.kind != 0 || c.stats_in || c.c2)) return fail("conv: folded init_conv needs a plain 3x3 conv");
   const size_t init_f = c.init_x ? (size_t)g.ni * c.init_cin * (g.hth + 2) * (g.htw + 2) + 4 + (size_t)c.init_cin * 9 * 64 + 64 + 8 : 0;
@@ -193,7 +201,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
 #endif
   const int kc = (c.kind == 1) ? 32 : 64;
   const size_t np = (size_t)g.ni * g.hth * g.htw;
-  size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0) + (fused_up ? 128 : 0) + init_f;
+  size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (fused_up ? 128 : 0) + init_f;
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
   if (lds_f < epi_f) lds_f = epi_f;
   if (c.bf16) {
@@ -205,6 +213,11 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   if (lds > 160 * 1024) return fail("conv: tile needs %zu B of LDS (> 160 KiB)", lds);
   const int groups = (c.B + g.ni - 1) / g.ni;
   dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), (c.kind == 2 && !fused_up) ? 4u : 1u);
+  a.ntiles = (int)grid.x;
+  if (!c.bf16) {  // persistent fp32 kernel: at most 3 resident workgroups per CU (256 CUs)
+    const unsigned resident = 768u / (grid.y * grid.z) ? 768u / (grid.y * grid.z) : 1u;
+    if (grid.x > resident) grid.x = resident;
+  }
   if (c.bf16) {
     if (c.kind == 0) return g.MT == 128 ? launch_conv_bf16_t<2, 0>(a, grid, lds, s) : launch_conv_bf16_t<1, 0>(a, grid, lds, s);
     if (c.kind == 2) return g.MT == 128 ? launch_conv_bf16_t<2, 2>(a, grid, lds, s) : launch_conv_bf16_t<1, 2>(a, grid, lds, s);

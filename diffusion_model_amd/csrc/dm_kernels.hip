@@ -22,6 +22,11 @@ __device__ __forceinline__ float dm_silu(float v) {
   // every staged element, and the full-precision divide alone cost ~13% of the conv kernel
   return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
+// SiLU(v) + t in 5 instructions: mul, v_exp_f32 (= exp2), add, v_rcp_f32, fma
+__device__ __forceinline__ float dm_silu_add(float v, float t) {
+  const float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+  return fmaf(v, __builtin_amdgcn_rcpf(1.0f + e), t);
+}
 
 // ------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on fp32 MFMA.
@@ -71,6 +76,9 @@ struct ConvArgs {
   int hth, htw;           // halo tile dims (input pixels)
   unsigned mg_htw, mg_hth; // ceil(2^32/d) magic dividers
   int pout;               // output partials per image
+  int h_log, w_log, c1_log, c2_log, cout_log;  // log2 of H, W, C1, C2, Cout (all powers of two)
+  int ppp_q, ppp_r;       // (pixels staged per workgroup load) = ppp_q * htw + ppp_r
+  int ntiles;             // tiles along grid.x (persistent kernels loop: t = blockIdx.x; t < ntiles; t += gridDim.x)
   // init_conv folded into this conv's staging (KIND 0, down1.conv1): when init_x != null the input
   // tile is COMPUTED from the NCHW image (3x3 conv, init_cin -> C1 channels) instead of loaded
   const float* init_x;    // [B, init_cin, H, W]
@@ -86,6 +94,11 @@ struct ConvArgs {
 #define DM_STAMP(k) do { if (p.stamps && threadIdx.x == 0) { size_t o_ = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; p.stamps[o_ + (k)] = __builtin_amdgcn_s_memtime(); if ((k) == 0 || (k) == 3) p.stamps[o_ + 4 + ((k) == 3)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define DM_STAMP(k) do {} while (0)
+#endif
+#ifdef DM_STAMPS
+#define DM_STAMP_RAW(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DM_STAMP_RAW(slot) do {} while (0)
 #endif
 
 // Epilogue of conv_mfma_kernel for one set of accumulators: + bias; GroupNorm partial statistics;
@@ -339,10 +352,9 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   DM_STAMP(0);
-  // Staging and epilogue run at raised wave priority, the K loop at 0: the SIMD arbitrates by
-  // priority, then age, so without this a workgroup that is staging (younger) only gets the
-  // issue slots the co-resident MFMA loops leave over and its 12 loads/thread crawl (measured:
-  // staging took 1.5x a whole K loop).  An MFMA loop needs few issue slots and does not suffer.
+  // Staging and epilogue ask for raised wave priority, the K loop for 0.  (Measured effect: small.
+  // The fp32 MFMA executes on the SIMD's fp32 lanes, so other waves' VALU work does not overlap
+  // it whatever the priority: scratch/ub/valu_starve.hip.)
   __builtin_amdgcn_s_setprio(2);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -354,23 +366,14 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   int py = par >> 1, px = par & 1;
   const int th = 1 << p.th_log, tw = 1 << p.tw_log;
 
-  // ---- tile decode
-  const int t = blockIdx.x;
-  const int img0 = (t / p.tiles_per_img) * p.ni;
-  const int tin = t % p.tiles_per_img;
-  const int y0 = (tin / p.tiles_x) << p.th_log;
-  const int x0 = (tin % p.tiles_x) << p.tw_log;
-  const int hy0 = (KIND == 0 || KIND == 4) ? y0 - 1 : (KIND == 1) ? 2 * y0 - 1 : (KIND == 2) ? y0 - 1 + py : y0;
-  const int hx0 = (KIND == 0 || KIND == 4) ? x0 - 1 : (KIND == 1) ? 2 * x0 - 1 : (KIND == 2) ? x0 - 1 + px : x0;
   const int hth = p.hth, htw = p.htw;
   const int NP = p.ni * hth * htw;
 
-  // ---- LDS carve: [mean ni*C1][scale ni*C1][beta C1][temb ni*C1][tile NP*RS]
+  // ---- LDS carve: [scale ni*C1][shift ni*C1][temb ni*C1][tile NP*RS]
   const bool tf = p.stats_in != nullptr;
-  float* s_mean = smem;
-  float* s_scale = s_mean + (tf ? p.ni * p.C1 : 0);
-  float* s_beta = s_scale + (tf ? p.ni * p.C1 : 0);
-  float* s_temb = s_beta + (tf ? p.C1 : 0);
+  float* s_scale = smem;
+  float* s_shift = s_scale + (tf ? p.ni * p.C1 : 0);
+  float* s_temb = s_shift + (tf ? p.ni * p.C1 : 0);
   float* tile = s_temb + (tf ? p.ni * p.C1 : 0);
 
   // ---- per-lane A-fragment base offsets (floats) into the halo tile at tap (0,0)
@@ -392,7 +395,21 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   const int nchunks = Cin / KC;
   constexpr int V = KC / 4;
   constexpr int U = 12;  // global loads in flight per thread while staging (one batch covers a tile)
-  const int items = NP * V;
+
+  // Persistent workgroups: the grid is at most 3 per CU and each workgroup walks tiles
+  // t, t + gridDim.x, ...  (a finished workgroup's slot otherwise stays empty for 2-16 k cycles
+  // until the dispatcher refills it: ~4 % of a CU's time at 160 k cycles per tile)
+  for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+  // opaque copy of the thread id: index math derived from it is recomputed per tile instead of
+  // being hoisted out of this loop and held in (spilled) registers across the K loop
+  int tq = threadIdx.x;
+  asm volatile("" : "+v"(tq));
+  const int img0 = (t / p.tiles_per_img) * p.ni;
+  const int tin = t % p.tiles_per_img;
+  const int y0 = (tin / p.tiles_x) << p.th_log;
+  const int x0 = (tin % p.tiles_x) << p.tw_log;
+  const int hy0 = (KIND == 0 || KIND == 4) ? y0 - 1 : (KIND == 1) ? 2 * y0 - 1 : (KIND == 2) ? y0 - 1 + py : y0;
+  const int hx0 = (KIND == 0 || KIND == 4) ? x0 - 1 : (KIND == 1) ? 2 * x0 - 1 : (KIND == 2) ? x0 - 1 + px : x0;
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int cg0 = chunk * KC;
@@ -409,80 +426,106 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
     // ---- stage: global -> (transform) -> LDS, U loads in flight per thread (HBM latency
     // is ~2 us under load; one load at a time would make this phase latency-bound)
     if (KIND == 0 && p.init_x) {
-      stage_init_tile<false, RS>(p, tile, tile + NP * RS, cg0, img0, hy0, hx0, hth, htw, tid);
+      stage_init_tile<false, RS>(p, tile, tile + NP * RS, cg0, img0, hy0, hx0, hth, htw, tq);
     } else
-    for (int base = 0; base < items; base += 256 * U) {  // uniform trip count (barrier inside)
-      float4 v[U];
-      int meta[U];  // (LDS float offset) | (table offset + 1) << 16; table part 0 = no transform
+    {
+      // Every VALU instruction here is paid for in MFMA time: the fp32 MFMA runs on the SIMD's
+      // fp32 lanes, so a co-resident wave's vector work does not overlap it (measured: a VALU wave
+      // beside two back-to-back MFMA waves makes no progress until they finish).  Hence: the
+      // thread's channel quad is fixed, the halo pixel advances by 256/V per load with
+      // add/compare/select instead of divisions, offsets are 32-bit shifts, tables are hoisted.
+      constexpr int PPP = 256 / V;                 // pixels covered by one load of the workgroup
+      const int c4 = tq & (V - 1), p0 = tq / V;
+      const int r0 = __umulhi((unsigned)p0, p.mg_htw);
+      int hx = p0 - r0 * htw;
+      int ii = __umulhi((unsigned)r0, p.mg_hth);
+      int hy = r0 - ii * hth;
+      const int cs_log = from2 ? p.c2_log : p.c1_log;
+      const float* srcb = src + ((size_t)img0 << (p.h_log + p.w_log + cs_log)) + coff + c4 * 4;
+      const int imax = p.B - 1 - img0;             // clamp for images past the batch
+      int pix = p0, lofs = p0 * RS + c4 * 4;
+      for (int base = 0; base < NP; base += PPP * U) {  // uniform trip count (barrier inside)
+        float4 v[U];
+        int meta[U];  // (LDS float offset) | (table offset + 1) << 16; table part 0 = zero fill
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = base + u * 256 + tid;
-        const int pix = idx / V, c4 = idx - pix * V;
-        const int r = __umulhi((unsigned)pix, p.mg_htw);
-        const int hx = pix - r * htw;
-        const int i = __umulhi((unsigned)r, p.mg_hth);
-        const int hy = r - i * hth;
-        const int iy = hy0 + hy, ix = hx0 + hx, n = img0 + i;
-        meta[u] = (idx < items) ? pix * RS + c4 * 4 : -1;
-        // The load is UNCONDITIONAL from a clamped (always valid) address and the padding is a
-        // select afterwards: a load under a runtime condition makes hipcc branch around it and
-        // wait vmcnt(0) each time, which serialises the 12 loads (~2 us apiece).
-        const bool inb = idx < items && n < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const int cn = min(n, p.B - 1), cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-        const int cc = (idx < items) ? c4 * 4 : 0;
-        v[u] = *reinterpret_cast<const float4*>(src + (((size_t)cn * p.H + cy) * p.W + cx) * Cs + coff + cc);
-        // zero padding / images past the batch stay exactly 0 and get no transform
-        if (inb) meta[u] |= (i * p.C1 + coff + c4 * 4 + 1) << 16;
-      }
-      if (tf && chunk == 0 && base == 0) {
-        // GroupNorm tables, computed while the first batch of tile loads is in flight
-        const int G = p.C1 / DM_GROUPS;
-        const int step = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
-        const float* te = p.temb ? p.temb + (size_t)step * p.temb_step_stride : nullptr;
-        for (int idx = tid; idx < p.ni * p.C1; idx += 256) {
-          const int i = idx / p.C1, c = idx - i * p.C1;
-          const int n = img0 + i;
-          float mean = 0.f, scale = 0.f, tv = 0.f;
-          if (n < p.B) {
-            const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c / G)) * 2;
-            float msum = 0.f;
-            for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
-            mean = msum / (float)p.pin;
-            float m2 = 0.f, dev = 0.f;
-            for (int q = 0; q < p.pin; ++q) {
-              const float d = st[q * DM_GROUPS * 2] - mean;
-              m2 += st[q * DM_GROUPS * 2 + 1];
-              dev += d * d;
-            }
-            const float var = (m2 + p.cnt_in * dev) / (p.cnt_in * (float)p.pin);
-            scale = rsqrtf(var + DM_GN_EPS) * p.gamma[c];
-            if (te) tv = te[(size_t)n * p.temb_stride + c];
-          }
-          s_mean[idx] = mean;
-          s_scale[idx] = scale;
-          s_temb[idx] = tv;
+        for (int u = 0; u < U; ++u) {
+          const int iy = hy0 + hy, ix = hx0 + hx;
+          const bool valid = pix < NP;
+          // The load is UNCONDITIONAL from a clamped (always valid) address and the padding is a
+          // select afterwards: a load under a runtime condition makes hipcc branch around it and
+          // wait vmcnt(0) each time, which serialises the loads (~2 us apiece).
+          const bool inb = valid && ii <= imax && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          const int cn = min(ii, imax), cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+          const unsigned off = (unsigned)((((cn << p.h_log) + cy) << p.w_log) + cx) << cs_log;
+          v[u] = *reinterpret_cast<const float4*>(srcb + off);
+          // zero padding / images past the batch stay exactly 0 and get no transform
+          meta[u] = valid ? (lofs | (inb ? (((ii << p.c1_log) + coff + c4 * 4 + 1) << 16) : 0)) : -1;
+          pix += PPP; lofs += PPP * RS;
+          hx += p.ppp_r; hy += p.ppp_q;
+          if (hx >= htw) { hx -= htw; ++hy; }
+          while (hy >= hth) { hy -= hth; ++ii; }
         }
-        for (int c = tid; c < p.C1; c += 256) s_beta[c] = p.beta[c];
-        __syncthreads();  // uniform condition
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (meta[u] >= 0) {
-          float4 w = v[u];
-          const int lofs = meta[u] & 0xffff, tofs = (meta[u] >> 16) - 1;
-          if (tofs < 0) w = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (tf && tofs >= 0) {
-            const int c = coff + (lofs % RS);
-            const float4 mu = *reinterpret_cast<const float4*>(s_mean + tofs);
-            const float4 sc = *reinterpret_cast<const float4*>(s_scale + tofs);
-            const float4 be = *reinterpret_cast<const float4*>(s_beta + c);
-            const float4 te = *reinterpret_cast<const float4*>(s_temb + tofs);
-            w.x = (w.x - mu.x) * sc.x + be.x; w.y = (w.y - mu.y) * sc.y + be.y;
-            w.z = (w.z - mu.z) * sc.z + be.z; w.w = (w.w - mu.w) * sc.w + be.w;
-            if (p.tf_silu) { w.x = dm_silu(w.x); w.y = dm_silu(w.y); w.z = dm_silu(w.z); w.w = dm_silu(w.w); }
-            w.x += te.x; w.y += te.y; w.z += te.z; w.w += te.w;
+        if (tf && chunk == 0 && base == 0) {
+          // GroupNorm tables (scale, shift = beta - mean*scale, temb per (image, channel)),
+          // computed while the first batch of tile loads is in flight
+          const int G = p.C1 / DM_GROUPS;
+          const int step = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
+          const float* te = p.temb ? p.temb + (size_t)step * p.temb_step_stride : nullptr;
+          for (int idx = tq; idx < p.ni * p.C1; idx += 256) {
+            const int i = idx >> p.c1_log, c = idx & (p.C1 - 1);
+            const int n = img0 + i;
+            float scale = 0.f, shift = 0.f, tv = 0.f;
+            if (n < p.B) {
+              const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c / G)) * 2;
+              float msum = 0.f;
+              for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
+              const float mean = msum / (float)p.pin;
+              float m2 = 0.f, dev = 0.f;
+              for (int q = 0; q < p.pin; ++q) {
+                const float d = st[q * DM_GROUPS * 2] - mean;
+                m2 += st[q * DM_GROUPS * 2 + 1];
+                dev += d * d;
+              }
+              const float var = (m2 + p.cnt_in * dev) / (p.cnt_in * (float)p.pin);
+              scale = rsqrtf(var + DM_GN_EPS) * p.gamma[c];
+              shift = p.beta[c] - mean * scale;
+              if (te) tv = te[(size_t)n * p.temb_stride + c];
+            }
+            s_scale[idx] = scale;
+            s_shift[idx] = shift;
+            s_temb[idx] = tv;
           }
-          *reinterpret_cast<float4*>(tile + lofs) = w;
+          __syncthreads();  // uniform condition
+        }
+        float4 hsc, hsh;  // with one image per tile the thread's table entries never change
+        if (tf && p.ni == 1) {
+          hsc = *reinterpret_cast<const float4*>(s_scale + coff + c4 * 4);
+          hsh = *reinterpret_cast<const float4*>(s_shift + coff + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (meta[u] >= 0) {
+            float4 w = v[u];
+            const int lo = meta[u] & 0xffff, tofs = (meta[u] >> 16) - 1;
+            if (tofs < 0) w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tf && tofs >= 0) {
+              float4 sc = hsc, sh = hsh;
+              const float4 te = *reinterpret_cast<const float4*>(s_temb + tofs);
+              if (p.ni != 1) {
+                sc = *reinterpret_cast<const float4*>(s_scale + tofs);
+                sh = *reinterpret_cast<const float4*>(s_shift + tofs);
+              }
+              w.x = fmaf(w.x, sc.x, sh.x); w.y = fmaf(w.y, sc.y, sh.y);
+              w.z = fmaf(w.z, sc.z, sh.z); w.w = fmaf(w.w, sc.w, sh.w);
+              if (p.tf_silu) {
+                w.x = dm_silu_add(w.x, te.x); w.y = dm_silu_add(w.y, te.y);
+                w.z = dm_silu_add(w.z, te.z); w.w = dm_silu_add(w.w, te.w);
+              } else {
+                w.x += te.x; w.y += te.y; w.z += te.z; w.w += te.w;
+              }
+            }
+            *reinterpret_cast<float4*>(tile + lo) = w;
+          }
         }
       }
     }
@@ -546,7 +589,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
         // one output parity is complete: store it (registers -> HBM; the input tile stays in
         // LDS for the next parity), emit its statistics partial, restart the accumulators
         par = tap >> 2; py = par >> 1; px = par & 1;
-        conv_epilogue<MB, KIND>(p, acc, tile + NP * RS, nullptr, par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
+        conv_epilogue<MB, KIND>(p, acc, tile + NP * RS, nullptr, par, py, px, img0, tin, y0, x0, (tq >> 7) & 1, (tq >> 6) & 1, tq & 63, (tq >> 5) & 1, tq, tq >> 6);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -559,9 +602,19 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   __builtin_amdgcn_s_setprio(2);
   if (KIND != 4) {
     __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
-    conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
+    conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, (tq >> 7) & 1, (tq >> 6) & 1, tq & 63, (tq >> 5) & 1, tq, tq >> 6);
   }
+  __syncthreads();  // LDS (output staging / reduction words) is free again for the next tile
+  }  // tile loop
   DM_STAMP(3);
+#ifdef DM_STAMPS
+  if (p.stamps && threadIdx.x == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + 6] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
 }
 
 // Pack a conv weight into MFMA B-fragment order (see conv_mfma_kernel).
