@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   DM_STAMP(0);
   // Staging and epilogue ask for raised wave priority, the K loop for 0.  (Measured effect: small.
   // The fp32 MFMA executes on the SIMD's fp32 lanes, so other waves' VALU work does not overlap
-  // it whatever the priority: scratch/ub/valu_starve.hip.)
+  // it whatever the priority: tools/diag/valu_starve.hip.)
   __builtin_amdgcn_s_setprio(2);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
