@@ -166,7 +166,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.cfg:
         from oracle import unet_oracle as O
         sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
-        cb = 128
+        cb = 512  # ~10 s of CPU work on the 16 host cores of the GPU box
         xc = x_T[:cb].cpu()
         O.sample(sd, O.make_schedule(), xc.shape, 2, 0.0, x_T=xc)  # warm-up
         t0 = time.perf_counter()

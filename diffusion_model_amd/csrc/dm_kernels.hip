@@ -417,8 +417,12 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
     const float* src = from2 ? p.x2 : p.x1;
     const int Cs = from2 ? p.C2 : p.C1;
     const int coff = from2 ? cg0 - p.C1 : cg0;
-    const float* wbase = p.wp + ((size_t)par * NT) * tapstride + (size_t)chunk * NJ * jstride +
-                         (size_t)(blockIdx.y * 2 + wn) * 256 + lane * 4;
+    // wave-uniform (scalar) part of the weight address + a per-lane 16-byte offset: lets the
+    // compiler use the saddr form of global_load instead of 64-bit vector adds per load
+    const int wn_s = __builtin_amdgcn_readfirstlane(wn);
+    const float* wuni = p.wp + ((size_t)par * NT) * tapstride + (size_t)chunk * NJ * jstride +
+                        (size_t)(blockIdx.y * 2 + wn_s) * 256;
+    const float* wbase = wuni + lane * 4;
     if (chunk > 0) {
       __builtin_amdgcn_s_setprio(2);
       __syncthreads();
