@@ -48,18 +48,29 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("DM_BENCH_WATCHDOG"):  # rehearsal aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DM_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # rehearsal aid: DM_BENCH_BACKEND=gloo DM_BENCH_ONE_DEVICE=1 runs N ranks on ONE GPU (RCCL refuses
+    # two ranks on a device); the driver's real runs use the defaults (nccl = RCCL, one GPU per rank)
+    backend = os.environ.get("DM_BENCH_BACKEND", "nccl")
+    if os.environ.get("DM_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import diffusion_model_amd as d
     from diffusion_model_amd import _lib

@@ -40,7 +40,12 @@ def sample_sharded(sample_fn: Callable[[torch.Tensor, Optional[torch.Tensor]], t
     if world == 1 or not gather:
         return out
     full = torch.empty((x_T_full.shape[0],) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
-    dist.all_gather_into_tensor(full, out, group=group)
+    if dist.get_backend(group) == "gloo":  # CPU tests / one-GPU rehearsal: gloo gathers host tensors
+        parts = [torch.empty(out.shape, dtype=out.dtype) for _ in range(world)]
+        dist.all_gather(parts, out.cpu(), group=group)
+        full.copy_(torch.cat(parts))
+    else:
+        dist.all_gather_into_tensor(full, out, group=group)
     return full
 
 
