@@ -40,7 +40,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per pass")
-    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--ddim-steps", type=int, default=50, help="number of sampler steps (both samplers)")
+    ap.add_argument("--sampler", default="ddim", choices=["ddim", "ancestral"],
+                    help="ancestral with --ddim-steps 1000 --batch 64 --eta 1 = BASELINE configs[0] (not the default metric)")
+    ap.add_argument("--eta", type=float, default=None, help="default 0 for ddim, 1 for ancestral")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = BASELINE configs[3] arithmetic (not the default metric)")
     ap.add_argument("--cfg", action="store_true", help="class-conditional + classifier-free guidance (doubled batch)")
@@ -79,13 +82,17 @@ def main():
     d.set_seed(42)
     model = d.UNetMini(image_size=32, precision=args.precision).eval()  # random-init weights, reference architecture
     sched = d.DDPMScheduler()
-    smp = d.DDIMSampler(sched, num_inference_steps=n, eta=0.0)
+    eta = args.eta if args.eta is not None else (0.0 if args.sampler == "ddim" else 1.0)
+    smp = d.create_sampler(args.sampler, sched, num_inference_steps=n, eta=eta)
     # synthetic x_T: the full [world*B] draw, each rank takes its row slice
     from diffusion_model_amd.distributed import sample_sharded, sampler_fn
     g = torch.Generator().manual_seed(42)
     x_T_full = torch.randn((world * B, 1, 32, 32), generator=g).to(dev)  # same draw on every rank
     x_T = x_T_full[rank * B:(rank + 1) * B]
     fn = sampler_fn(smp, model)
+    if eta > 0:  # per-step noise of this rank's rows, resident in HBM like x_T
+        nz_local = torch.randn((n, B, 1, 32, 32), generator=torch.Generator().manual_seed(43 + rank)).to(dev)
+        fn = lambda x, nz: smp.sample_from(model, x, nz_local)
     if args.cfg:  # build-defined guided sampling: labels arange % 10, null class 10, w = 3
         cc = d.ClassConditioner(11, 128)
         cond_full = cc(torch.arange(world * B) % 10)
@@ -119,12 +126,13 @@ def main():
     images = world * B * args.steps
     value = images / dt
     res = {
-        "metric": "sampled images/sec (DDIM-50, 32x32 MNIST UNet)", "value": value, "unit": "images/s",
+        "metric": f"sampled images/sec ({'DDIM' if args.sampler == 'ddim' else 'DDPM-ancestral'}-{n}, 32x32 MNIST UNet)", "value": value, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-        "config": {"workload": f"DDIM-{n} eta=0, UNetMini(32x32, C=64) random-init seed 42, batch {B} per GPU, "
-                               "x_T resident in HBM (BASELINE configs[1])",
+        "config": {"workload": f"{args.sampler.upper()}-{n} eta={eta:g}, UNetMini(32x32, C=64) random-init seed 42, batch {B} per GPU, "
+                               "x_T resident in HBM"
+                               + (" (BASELINE configs[1])" if (args.sampler, n, eta, B) == ("ddim", 50, 0.0, 1024) else ""),
                    "images_per_gpu": B, "ddim_steps": n, "guidance": bool(args.cfg), "parallelism": f"dp{world} (batch-sharded, final all-gather)"},
         "achieved_tflops_whole_path": value * n * FLOP_PER_IMAGE_STEP / 1e12,
         "frac_fp32_mfma_peak_whole_path": value * n * FLOP_PER_IMAGE_STEP / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
@@ -179,12 +187,15 @@ def main():
         sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
         cb = 512  # ~10 s of CPU work on the 16 host cores of the GPU box
         xc = x_T[:cb].cpu()
+        cb = min(cb, B)
+        xc = x_T[:cb].cpu()
+        nzc = nz_local[:, :cb].cpu() if eta > 0 else None
         O.sample(sd, O.make_schedule(), xc.shape, 2, 0.0, x_T=xc)  # warm-up
         t0 = time.perf_counter()
-        ref = O.sample(sd, O.make_schedule(), xc.shape, n, 0.0, x_T=xc)
+        ref = O.sample(sd, O.make_schedule(), xc.shape, n, eta, x_T=xc, noises=nzc)
         ct = time.perf_counter() - t0
         res["cpu_baseline"] = {"value": cb / ct, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"CPU oracle (torch-CPU restatement of the reference sampler), DDIM-{n}, batch {cb}, "
+                               "sample": f"CPU oracle (torch-CPU restatement of the reference sampler), {args.sampler}-{n} eta={eta:g}, batch {cb}, "
                                          f"{ct:.1f} s"}
         err = (out[:cb].cpu() - ref).abs().max().item()
         res["check_max_abs_vs_cpu_oracle"] = err

@@ -127,6 +127,21 @@ def test_ancestral20_free_running(golden, model):
     assert O.psnr(out, ref, float(ref.max() - ref.min())).min().item() >= 40.0
 
 
+def test_ancestral1000_graph_chunks_equal_eager(model):
+    """BASELINE configs[0] shape of loop (T=1000, eta=1): 20 replays of the 50-step graph with the
+    device-side step counter must reproduce the eagerly launched loop bit for bit."""
+    sched = d.DDPMScheduler()
+    smp = d.AncestralSampler(sched, num_inference_steps=1000, eta=1.0)
+    g = torch.Generator().manual_seed(5)
+    x_T = torch.randn((3, 1, 32, 32), generator=g)
+    nz = torch.randn((1000, 3, 1, 32, 32), generator=g)
+    smp.use_graph = False
+    a = smp.sample_from(model, x_T, nz)
+    smp.use_graph = True
+    b = smp.sample_from(model, x_T, nz)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_generic_model_callable_path(golden, model):
     """Any callable model is driven step by step through scheduler.step (sample.py:245-254 style)."""
     sched = d.DDPMScheduler()
