@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_IMAGE_STEP = 364_249_088  # SURVEY 8(d), equals torch.utils.flop_counter on model.py:120-151
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak
 K_NAMES = ["init_conv", "conv3x3_mfma_t128", "conv3x3_mfma_t64", "conv4x4s2_mfma", "convT4x4s2_mfma_t128",
-           "convT4x4s2_mfma_t64", "final_conv", "time_embed", "sampler_step", "attention"]
+           "convT4x4s2_mfma_t64", "final_conv", "time_embed", "sampler_step", "attention", "conv3x3_winograd_mfma"]
 NK = len(K_NAMES)  # DM_K_COUNT
 
 
@@ -159,10 +159,10 @@ def main():
             if counts[k]:
                 per[K_NAMES[k]] = {"launches": counts[k], "avg_us": 1e3 * ms[k] / counts[k], "share": ms[k] / tot_ms,
                                    "tflops": fl[k] / (ms[k] * 1e-3) / 1e12, "alg_gbps": by[k] / (ms[k] * 1e-3) / 1e9}
-        k = 1  # dominant: conv_mfma_kernel<2,0,64>
+        k = 1 if args.precision == "bf16" else 10  # dominant: conv_bf16_kernel<2,0> / conv_mfma_kernel<2,5,64> (DM_K_WINO)
         ach = fl[k] / (ms[k] * 1e-3) / 1e12
         traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic_wino.json")
         if os.path.exists(tpath) and B == 1024:
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
         if args.precision == "bf16":
@@ -173,7 +173,9 @@ def main():
                                "traffic": None, "avg_launch_us": 1e3 * ms[k] / counts[k],
                                "algorithmic_bytes_per_launch": by[k] / counts[k], "share_of_denoiser_time": ms[k] / tot_ms}
         else:
-          res["roofline"] = {"kernel": "conv_mfma_kernel<2,0,64> (3x3 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+          res["roofline"] = {"kernel": "conv_mfma_kernel<2,5,64> (3x3 conv as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32; "
+                                       "achieved = ALGORITHMIC direct-conv FLOPs / time, the kernel executes 4/9 of them)",
+                             "executed_mfma_frac": ach * (4.0 / 9.0) / PEAK_FP32_MFMA_TFLOPS,
                              "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                              "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, B=1024)",
@@ -199,6 +201,9 @@ def main():
                                          f"{ct:.1f} s"}
         err = (out[:cb].cpu() - ref).abs().max().item()
         res["check_max_abs_vs_cpu_oracle"] = err
+        if eta == 0 and n <= 50 and args.precision == "fp32" and not err <= 1e-3:
+            # a throughput number for wrong samples is worthless: refuse to print one
+            raise SystemExit(f"bench: GPU samples differ from the CPU oracle by {err:.3g} (> 1e-3) on the first {cb} images")
 
     if rank == 0:
         print(json.dumps(res))

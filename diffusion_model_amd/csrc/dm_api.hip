@@ -80,7 +80,7 @@ ConvGeo conv_geo(int kind, int H, int W, int Cout) {
   g.OH = (kind == 1) ? H / 2 : (kind == 2) ? 2 * H : H;
   g.OW = (kind == 1) ? W / 2 : (kind == 2) ? 2 * W : W;
   const int npix = g.Hb * g.Wb;
-  g.MT = (kind == 1) ? 64 : (npix >= 256 ? 128 : 64);
+  g.MT = (kind == 1) ? 64 : (kind == 5 || npix >= 256) ? 128 : 64;  // kind 5 (Winograd): always 32 2x2-pixel tiles
   int tw = g.Wb < ((kind == 1) ? 8 : 16) ? g.Wb : ((kind == 1) ? 8 : 16);
   int th = g.Hb < g.MT / tw ? g.Hb : g.MT / tw;
   g.ni = g.MT / (th * tw);
@@ -126,11 +126,12 @@ int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     attr_done = true;
   }
   constexpr bool UP = (KIND == 2 || KIND == 4);
-  const int cls = KIND == 0 ? (MB == 2 ? DM_K_CONV3_128 : DM_K_CONV3_64)
+  const int cls = KIND == 5 ? DM_K_WINO : KIND == 0 ? (MB == 2 ? DM_K_CONV3_128 : DM_K_CONV3_64)
                             : KIND == 1 ? DM_K_DOWN : KIND == 3 ? DM_K_ATTN : (MB == 2 ? DM_K_UP_128 : DM_K_UP_64);
   const double opix = (double)a.B * a.Hb * a.Wb * (UP ? 4 : 1);
   const double ipix = (double)a.B * a.H * a.W;
-  const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : KIND == 3 ? 1 : 4;
+  // (KIND 5 books the ALGORITHMIC 3x3 count, 9 multiply-adds per tap set; it executes 4 per output)
+  const double taps = (KIND == 0 || KIND == 5) ? 9 : KIND == 1 ? 16 : KIND == 3 ? 1 : 4;
   const int cin = a.C1 + a.C2;
   ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 4.0 * (ipix * cin + opix * a.Cout + taps * (UP ? 4 : 1) * cin * a.Cout));
   hipLaunchKernelGGL((conv_mfma_kernel<MB, KIND, KC>), grid, dim3(256), lds, s, a);
@@ -159,7 +160,9 @@ int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
 
 int launch_conv(const ConvCall& c, hipStream_t s) {
   const int cin = c.c1 + c.c2;
-  if (c.kind < 0 || c.kind > 3) return fail("conv: unknown kind %d", c.kind);
+  if (c.kind < 0 || (c.kind > 3 && c.kind != 5)) return fail("conv: unknown kind %d", c.kind);
+  if (c.kind == 5 && (c.bf16 || c.res || c.H < 8 || c.W < 8))
+    return fail("conv: the Winograd 3x3 path is fp32, without residual, for H,W >= 8 (got %dx%d)", c.H, c.W);
   if (c.c1 % 64 || c.c2 % 64 || c.cout % 64) return fail("conv: channel counts must be multiples of 64 (got %d+%d -> %d)", c.c1, c.c2, c.cout);
   if (c.cout != 64 && c.cout != 128 && c.cout != 256 && c.cout != 512 && c.stats_out)
     return fail("conv: GroupNorm(8) statistics need Cout in {64,128,256,512} (got %d)", c.cout);
@@ -194,7 +197,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
     a.ppp_q = ppp / g.htw; a.ppp_r = ppp % g.htw;
   }
   a.init_x = c.init_x; a.init_w = c.init_w; a.init_b = c.init_b; a.init_cin = c.init_cin;
-  if (c.init_x && (c.kind != 0 || c.stats_in || c.c2)) return fail("conv: folded init_conv needs a plain 3x3 conv");
+  if (c.init_x && ((c.kind != 0 && c.kind != 5) || c.stats_in || c.c2)) return fail("conv: folded init_conv needs a plain 3x3 conv");
   const size_t init_f = c.init_x ? (size_t)g.ni * c.init_cin * (g.hth + 2) * (g.htw + 2) + 4 + (size_t)c.init_cin * 9 * 64 + 64 + 8 : 0;
 #ifdef DM_STAMPS
   a.stamps = g_stamps;
@@ -204,6 +207,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (fused_up ? 128 : 0) + init_f;
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
   if (lds_f < epi_f) lds_f = epi_f;
+  if (c.kind == 5 && lds_f < DM_WINO_EPI_FLOATS) lds_f = DM_WINO_EPI_FLOATS;
   if (c.bf16) {
     lds_f = (np * (64 + 8) + 1) / 2 + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0) + init_f;
     const size_t e2 = (size_t)g.MT * 36 + 128;
@@ -214,8 +218,9 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   const int groups = (c.B + g.ni - 1) / g.ni;
   dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), (c.kind == 2 && !fused_up) ? 4u : 1u);
   a.ntiles = (int)grid.x;
-  if (!c.bf16) {  // persistent fp32 kernel: at most 3 resident workgroups per CU (256 CUs)
-    const unsigned resident = 768u / (grid.y * grid.z) ? 768u / (grid.y * grid.z) : 1u;
+  if (!c.bf16) {  // persistent fp32 kernel: at most 3 (Winograd: 2) resident workgroups per CU (256 CUs)
+    const unsigned slots = c.kind == 5 ? 512u : 768u;
+    const unsigned resident = slots / (grid.y * grid.z) ? slots / (grid.y * grid.z) : 1u;
     if (grid.x > resident) grid.x = resident;
   }
   if (c.bf16) {
@@ -223,6 +228,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
     if (c.kind == 2) return g.MT == 128 ? launch_conv_bf16_t<2, 2>(a, grid, lds, s) : launch_conv_bf16_t<1, 2>(a, grid, lds, s);
     return launch_conv_bf16_t<1, 1>(a, grid, lds, s);
   }
+  if (c.kind == 5) return launch_conv_t<2, 5, 64>(a, grid, lds, s);
   if (fused_up) return g.MT == 128 ? launch_conv_t<2, 4, 64>(a, grid, lds, s) : launch_conv_t<1, 4, 64>(a, grid, lds, s);
   (void)cin;
   if (c.kind == 0) return g.MT == 128 ? launch_conv_t<2, 0, 64>(a, grid, lds, s) : launch_conv_t<1, 0, 64>(a, grid, lds, s);
@@ -232,7 +238,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
 }
 
 size_t conv_packed_floats(int kind, int cin, int cout) {
-  const int taps = kind == 0 ? 9 : kind == 3 ? 1 : 16;  // KIND 2: 4 parities x 4 taps
+  const int taps = kind == 0 ? 9 : kind == 3 ? 1 : 16;  // KIND 2: 4 parities x 4 taps; KIND 5: 16 transform points
   return (size_t)taps * cin * cout;
 }
 
@@ -240,13 +246,14 @@ int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream
   if (cin % 16 || cout % 32) return fail("pack_conv: cin %% 16 / cout %% 32");
   const size_t total = conv_packed_floats(kind, cin, cout);
   if (bf16) {
-    if (kind == 3) return fail("pack_conv: no bf16 1x1 variant");
+    if (kind == 3 || kind == 5) return fail("pack_conv: no bf16 1x1 / Winograd variant");
     hipLaunchKernelGGL(pack_conv_weight_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind, w, cin, cout,
                        reinterpret_cast<bf16_t*>(out), total);
     HIP_TRY(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind, w, cin, cout, out, total);
+  if (kind == 5) hipLaunchKernelGGL(pack_wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, cin, cout, out, total);
+  else hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind, w, cin, cout, out, total);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -254,7 +261,7 @@ int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream
 }  // namespace
 
 // ------------------------------------------------------------------ model container
-struct BlockOff { size_t tmw, tmb, c1, c1b, c2, c2b, tr, trb, g1, b1, g2, b2; };
+struct BlockOff { size_t tmw, tmb, c1, c1b, c2, c2b, tr, trb, g1, b1, g2, b2, c1w, c2w; };  // c1w/c2w: Winograd form
 
 struct GraphEntry {
   const void *packed, *x, *ws, *coefs, *noise, *cond;
@@ -273,7 +280,7 @@ struct dm_unet {
   AttnOff att[2];
   size_t o_freqs, o_tm1w, o_tm1b, o_tm2w, o_tm2b, o_initw, o_initb;
   BlockOff blk[6];
-  size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb;
+  size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb, o_b0w, o_b3w;
   size_t total;
   std::vector<GraphEntry> graphs;
 };
@@ -424,20 +431,23 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     c.stats_in = si; c.pin = pg.pout; c.cnt_in = pg.cnt_out; c.gamma = P + g; c.beta = P + b;
   };
   // Block.forward (model.py:52-64); in: block input(s) at hxw
+  // 3x3 convolutions: Winograd F(2x2,3x3) in fp32 from 8x8 up, the direct form below that and in bf16
+  auto k3 = [&](int h, int ww) { return (!m->bf16 && h >= 8 && ww >= 8) ? 5 : 0; };
   auto block = [&](int k, const float* in1, const float* in2, int h, int ww, bool up, float* out, float* out_stats) -> int {
     const BlockOff& o = m->blk[k];
-    base(0, in1, C, in2, in2 ? C : 0, o.c1, o.c1b, w.T1, w.SA, h, ww);
+    const int kd = k3(h, ww);
+    base(kd, in1, C, in2, in2 ? C : 0, kd == 5 ? o.c1w : o.c1, o.c1b, w.T1, w.SA, h, ww);
     if (k == 0 && fold_init) {
       c.init_x = x; c.init_w = P + m->o_initw; c.init_b = P + m->o_initb; c.init_cin = m->Cin;
     }
     if (launch_conv(c, s)) return 1;
-    base(0, w.T1, C, nullptr, 0, o.c2, o.c2b, w.T2, w.SB, h, ww);
-    with_tf(w.SA, 0, h, ww, o.g1, o.b1);
+    base(kd, w.T1, C, nullptr, 0, kd == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
+    with_tf(w.SA, kd, h, ww, o.g1, o.b1);
     c.temb = heads + (size_t)k * C; c.temb_stride = heads_img_stride; c.temb_step_stride = heads_step_stride;
     c.step_ptr = step_ptr; c.step_off = step_off;
     if (launch_conv(c, s)) return 1;
     base(up ? 2 : 1, w.T2, C, nullptr, 0, o.tr, o.trb, out, out_stats, h, ww);
-    with_tf(w.SB, 0, h, ww, o.g2, o.b2);
+    with_tf(w.SB, kd, h, ww, o.g2, o.b2);
     return launch_conv(c, s);
   };
   if (block(0, w.A0, nullptr, H, W, false, w.D1, nullptr)) return 1;
@@ -448,10 +458,11 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   }
   if (block(2, w.D2, nullptr, H / 4, W / 4, false, w.D3, nullptr)) return 1;
   // bottleneck (model.py:98-103,143)
-  base(0, w.D3, C, nullptr, 0, m->o_b0, m->o_b0b, w.BT0, w.SA, H / 8, W / 8);
+  const int kb = k3(H / 8, W / 8);
+  base(kb, w.D3, C, nullptr, 0, kb == 5 ? m->o_b0w : m->o_b0, m->o_b0b, w.BT0, w.SA, H / 8, W / 8);
   if (launch_conv(c, s)) return 1;
-  base(0, w.BT0, C, nullptr, 0, m->o_b3, m->o_b3b, w.BT, nullptr, H / 8, W / 8);
-  with_tf(w.SA, 0, H / 8, W / 8, m->o_bg, m->o_bb);
+  base(kb, w.BT0, C, nullptr, 0, kb == 5 ? m->o_b3w : m->o_b3, m->o_b3b, w.BT, nullptr, H / 8, W / 8);
+  with_tf(w.SA, kb, H / 8, W / 8, m->o_bg, m->o_bb);
   if (launch_conv(c, s)) return 1;
   // up path: channel concat [upstream, skip] (model.py:146-148) handled by two input pointers
   if (block(3, w.BT, w.D3, H / 8, W / 8, true, w.U1, m->attn ? w.SA : nullptr)) return 1;
@@ -545,7 +556,9 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
     b.tr = take(conv_packed_floats(up ? 2 : 1, C, C)); b.trb = take(C);
     b.c2 = take(conv_packed_floats(0, C, C)); b.c2b = take(C);
     b.g1 = take(C); b.b1 = take(C); b.g2 = take(C); b.b2 = take(C);
+    b.c1w = take(conv_packed_floats(5, up ? 2 * C : C, C)); b.c2w = take(conv_packed_floats(5, C, C));
   }
+  m->o_b0w = take(conv_packed_floats(5, C, C)); m->o_b3w = take(conv_packed_floats(5, C, C));
   m->o_b0 = take(conv_packed_floats(0, C, C)); m->o_b0b = take(C);
   m->o_bg = take(C); m->o_bb = take(C);
   m->o_b3 = take(conv_packed_floats(0, C, C)); m->o_b3b = take(C);
@@ -601,13 +614,16 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
     const bool up = k >= 3;
     const BlockOff& b = m->blk[k];
     if (copy(b.tmw, p[i++], (size_t)C * E) || copy(b.tmb, p[i++], C)) return 1;
+    if (!m->bf16 && pack_conv(5, p[i], up ? 2 * C : C, C, packed + b.c1w, s)) return 1;
     if (pack_conv(0, p[i++], up ? 2 * C : C, C, packed + b.c1, s, m->bf16) || copy(b.c1b, p[i++], C)) return 1;
     if (pack_conv(up ? 2 : 1, p[i++], C, C, packed + b.tr, s, m->bf16) || copy(b.trb, p[i++], C)) return 1;
+    if (!m->bf16 && pack_conv(5, p[i], C, C, packed + b.c2w, s)) return 1;
     if (pack_conv(0, p[i++], C, C, packed + b.c2, s, m->bf16) || copy(b.c2b, p[i++], C)) return 1;
     if (copy(b.g1, p[i++], C) || copy(b.b1, p[i++], C) || copy(b.g2, p[i++], C) || copy(b.b2, p[i++], C)) return 1;
     return 0;
   };
   for (int k = 0; k < 3; ++k) if (do_block(k)) return 1;
+  if (!m->bf16 && (pack_conv(5, p[i], C, C, packed + m->o_b0w, s) || pack_conv(5, p[i + 4], C, C, packed + m->o_b3w, s))) return 1;
   if (pack_conv(0, p[i++], C, C, packed + m->o_b0, s, m->bf16) || copy(m->o_b0b, p[i++], C) ||
       copy(m->o_bg, p[i++], C) || copy(m->o_bb, p[i++], C) ||
       pack_conv(0, p[i++], C, C, packed + m->o_b3, s, m->bf16) || copy(m->o_b3b, p[i++], C)) return 1;
@@ -818,12 +834,12 @@ size_t dm_conv_packed_floats(int kind, int cin, int cout) { return conv_packed_f
 
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev, void* stream) {
   if (!w_dev || !packed_dev) return fail("dm_pack_conv_weight: null argument");
-  if (kind < 0 || kind > 3) return fail("unknown conv kind %d", kind);
+  if (kind < 0 || (kind > 3 && kind != 5)) return fail("unknown conv kind %d", kind);
   return pack_conv(kind, w_dev, cin, cout, packed_dev, (hipStream_t)stream);
 }
 
 int dm_conv_stats_partials(int kind, int H, int W) {
-  if (kind < 0 || kind > 3 || !is_pow2(H) || !is_pow2(W)) return 0;
+  if (kind < 0 || (kind > 3 && kind != 5) || !is_pow2(H) || !is_pow2(W)) return 0;
   return conv_geo(kind, H, W, 64).pout;
 }
 

@@ -115,7 +115,7 @@ __device__ __forceinline__ bf16_t f2bf(float f);
 // order as init_conv_kernel, so the result is bit-identical to the two-kernel form while the
 // 256 KiB/image write + re-read of the init activation disappears.  aux: LDS scratch for the
 // image patch (halo + 1) and the 64 output channels' weights.  Caller barriers afterwards.
-template <bool BF, int RSX>
+template <bool BF, int RSX, bool WINO = false>
 __device__ __forceinline__ void stage_init_tile(const ConvArgs& p, void* tile_v, float* aux, int chan0, int img0,
                                                 int hy0, int hx0, int hth, int htw, int tid) {
   const int Ci = p.init_cin;
@@ -164,13 +164,15 @@ __device__ __forceinline__ void stage_init_tile(const ConvArgs& p, void* tile_v,
           }
       }
     }
+    // Winograd kernel: the tile is stored as four (row parity, column parity) planes per image
+    const int lp = WINO ? ((i * 4 + (hy & 1) * 2 + (hx & 1)) * (hth >> 1) + (hy >> 1)) * (htw >> 1) + (hx >> 1) : pix;
     if (BF) {
       uint2 o;
       o.x = (unsigned)f2bf(a.x) | ((unsigned)f2bf(a.y) << 16);
       o.y = (unsigned)f2bf(a.z) | ((unsigned)f2bf(a.w) << 16);
-      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(tile_v) + pix * RSX + c4 * 4) = o;
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(tile_v) + lp * RSX + c4 * 4) = o;
     } else {
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(tile_v) + pix * RSX + c4 * 4) = a;
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(tile_v) + lp * RSX + c4 * 4) = a;
     }
   }
 }
@@ -340,9 +342,106 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
   }
 }
 
+// Epilogue of the Winograd kernel (KIND 5).  Wave i holds M[i][j] (j = 0..3) of 32 tiles x 64 channels:
+// the row half of the output transform (T[i][b] = sum_j M[i][j] A^T[b][j]) happens in registers, the
+// column half (Y[a][b] = sum_i A^T[a][i] T[i][b]) needs all four waves and goes through LDS.  Then, with
+// each thread holding 8 pixels x 4 channels of the finished tile: + bias, GroupNorm (mean, M2) partials
+// in a fixed summation order (independent of batch size and dispatch order), coalesced NHWC store.
+// LDS: T [4][2][32][68] floats, then 256 + 64 reduction words.
+#define DM_WINO_EPI_FLOATS (4 * 2 * 32 * 68 + 256 + 64)
+__device__ __forceinline__ void wino_epilogue(const ConvArgs& p, f32x16 (&acc)[8], float* smem, int img0, int tin,
+                                              int y0, int x0, int tq) {
+  constexpr int TRS = 68;
+  constexpr int PS = 2 * 32 * TRS;  // plane stride between waves
+  const int lane = tq & 63, wave = tq >> 6, h = lane >> 5, n32 = lane & 31;
+  float* Tb = smem;
+  float* sred = smem + 4 * PS;  // [4 waves][8 image slots][8 groups]
+  float* s_mu = sred + 256;     // [8 image slots][8 groups]
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0 + nb][r], m1 = acc[2 + nb][r], m2 = acc[4 + nb][r], m3 = acc[6 + nb][r];
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      float* q = Tb + wave * PS + row * TRS + nb * 32 + n32;
+      q[0] = (m0 + m1) + m2;
+      q[32 * TRS] = (m1 - m2) - m3;
+    }
+  __syncthreads();
+  const int th = 1 << p.th_log, tw = 1 << p.tw_log;
+  const int tsh = p.tw_log + p.th_log;  // log2(pixels of one image inside the tile)
+  const int c4 = tq & 15, p0 = tq >> 4;
+  const float4 bv = *reinterpret_cast<const float4*>(p.bias + blockIdx.y * 64 + c4 * 4);
+  float4 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int m = p0 + 16 * k;
+    const int x = m & (tw - 1), y = (m >> p.tw_log) & (th - 1), i = m >> tsh;
+    const int tl = (i << (tsh - 2)) | ((y >> 1) << (p.tw_log - 1)) | (x >> 1);
+    const int a = y & 1, b = x & 1;
+    const float* q = Tb + ((a * 2 + b) * 32 + tl) * TRS + c4 * 4;  // plane a: a = 0 sums T0+T1+T2, a = 1 T1-T2-T3
+    const float4 t0 = *reinterpret_cast<const float4*>(q);
+    const float4 t1 = *reinterpret_cast<const float4*>(q + PS);
+    const float4 t2 = *reinterpret_cast<const float4*>(q + 2 * PS);
+    const float sg = a ? -1.f : 1.f;
+    v[k].x = fmaf(sg, t2.x, fmaf(sg, t1.x, t0.x)) + bv.x;
+    v[k].y = fmaf(sg, t2.y, fmaf(sg, t1.y, t0.y)) + bv.y;
+    v[k].z = fmaf(sg, t2.z, fmaf(sg, t1.z, t0.z)) + bv.z;
+    v[k].w = fmaf(sg, t2.w, fmaf(sg, t1.w, t0.w)) + bv.w;
+  }
+  if (p.stats_out) {
+    const int G = p.Cout / DM_GROUPS;       // channels per group: 8, 16, 32 or 64
+    const int qg = G >> 2;                  // channel quads per group
+    const int gpt = 64 / G;                 // groups in this workgroup's 64 channels
+    const int gq = c4 / qg;
+    const int kk_log = tsh - 4;             // log2(k slots per image): rows of one image / 16
+    const float inv_cnt = 1.0f / (float)((1 << tsh) * G);
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int i = 0; i < p.ni; ++i) {
+        const float mu = pass ? s_mu[i * 8 + gq] : 0.f;
+        float sm = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float dx = v[k].x - mu, dy = v[k].y - mu, dz = v[k].z - mu, dw = v[k].w - mu;
+          const float part = pass ? (dx * dx + dy * dy) + (dz * dz + dw * dw) : (dx + dy) + (dz + dw);
+          sm += ((k >> kk_log) == i) ? part : 0.f;
+        }
+        for (int o = 1; o < qg && o < 16; o <<= 1) sm += __shfl_xor(sm, o, 64);
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        if ((lane >> 4) == 0 && (c4 & (qg - 1)) == 0) sred[(wave * 8 + i) * 8 + gq] = sm;
+      }
+      __syncthreads();
+      if (tq < p.ni * gpt) {
+        const int i = tq / gpt, g = tq - i * gpt;
+        const float sm = ((sred[(0 * 8 + i) * 8 + g] + sred[(1 * 8 + i) * 8 + g]) + sred[(2 * 8 + i) * 8 + g]) + sred[(3 * 8 + i) * 8 + g];
+        if (pass == 0) {
+          s_mu[i * 8 + g] = sm * inv_cnt;
+        } else {
+          const int n = img0 + i;
+          if (n < p.B) {
+            float* so = p.stats_out + (((size_t)n * p.pout + tin) * DM_GROUPS + blockIdx.y * gpt + g) * 2;
+            so[0] = s_mu[i * 8 + g];
+            so[1] = sm;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int m = p0 + 16 * k;
+    const int x = x0 + (m & (tw - 1)), y = y0 + ((m >> p.tw_log) & (th - 1)), n = img0 + (m >> tsh);
+    if (n < p.B)
+      *reinterpret_cast<float4*>(p.y + ((((size_t)n * p.H + y) * p.W + x) * p.Cout + blockIdx.y * 64 + c4 * 4)) = v[k];
+  }
+}
+
 template <int MB, int KIND, int KC>
-__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const ConvArgs p) {
   constexpr int MT = 64 * MB;
+  constexpr bool WINO = (KIND == 5);
   constexpr int RS = KC + 4;  // LDS row stride (floats): 16-B skew between consecutive pixels
   constexpr int S = (KIND == 1) ? 2 : 1;
   constexpr int NTY = (KIND == 0) ? 3 : (KIND == 1) ? 4 : (KIND == 2 || KIND == 4) ? 2 : 1;
@@ -379,7 +478,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   // ---- per-lane A-fragment base offsets (floats) into the halo tile at tap (0,0)
   int abase[MB];
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
+  for (int mb = 0; mb < MB && !WINO; ++mb) {
     const int m = wm * (32 * MB) + mb * 32 + (lane & 31);
     const int x = m & (tw - 1);
     const int y = (m >> p.tw_log) & (th - 1);
@@ -387,7 +486,29 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
     abase[mb] = ((i * hth + y * S) * htw + x * S) * RS + 4 * h;
   }
 
-  f32x16 acc[MB];  // zeroed after the first chunk is staged (keeps staging's register peak low)
+  // KIND 5 (Winograd): wave i owns the transform-domain points (i, 0..3) of the 32 2x2-pixel
+  // tiles, for both 32-channel halves: acc[j*2 + nb].  aoff: the lane's eight LDS reads per channel
+  // group — rows rA and rB of its tile's 4x4 input patch (B^T row i has two non-zeros), 4 columns.
+  int aoff[WINO ? 8 : 1];
+  float wsg = 0.f;
+  if constexpr (WINO) {
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int rA = (wv == 0) ? 0 : (wv == 2) ? 2 : 1;
+    const int rB = (wv == 0) ? 2 : (wv == 1) ? 2 : (wv == 2) ? 1 : 3;
+    wsg = (wv == 1) ? 1.f : -1.f;
+    const int PH = p.hth >> 1, PW = p.htw >> 1;
+    const int tl = lane & 31;
+    const int txw = tl & ((tw >> 1) - 1);
+    const int tyw = (tl >> (p.tw_log - 1)) & ((th >> 1) - 1);
+    const int iw = tl >> (p.tw_log + p.th_log - 2);
+    const int L0 = (iw * 4 * PH + tyw) * PW + txw;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = (q < 4) ? rA : rB, sc = q & 3;
+      aoff[q] = (L0 + (((r & 1) * 2 + (sc & 1)) * PH + (r >> 1)) * PW + (sc >> 1)) * RS + 4 * h;
+    }
+  }
+  f32x16 acc[WINO ? 8 : MB];  // zeroed after the first chunk is staged (keeps staging's register peak low)
 
   const int nb32 = p.Cout >> 5;
   const size_t jstride = (size_t)nb32 * 256;
@@ -404,12 +525,13 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
   // being hoisted out of this loop and held in (spilled) registers across the K loop
   int tq = threadIdx.x;
   asm volatile("" : "+v"(tq));
+  if (KIND == 4) { par = 0; py = 0; px = 0; }  // (advanced by the previous tile's K loop)
   const int img0 = (t / p.tiles_per_img) * p.ni;
   const int tin = t % p.tiles_per_img;
   const int y0 = (tin / p.tiles_x) << p.th_log;
   const int x0 = (tin % p.tiles_x) << p.tw_log;
-  const int hy0 = (KIND == 0 || KIND == 4) ? y0 - 1 : (KIND == 1) ? 2 * y0 - 1 : (KIND == 2) ? y0 - 1 + py : y0;
-  const int hx0 = (KIND == 0 || KIND == 4) ? x0 - 1 : (KIND == 1) ? 2 * x0 - 1 : (KIND == 2) ? x0 - 1 + px : x0;
+  const int hy0 = (KIND == 0 || KIND == 4 || KIND == 5) ? y0 - 1 : (KIND == 1) ? 2 * y0 - 1 : (KIND == 2) ? y0 - 1 + py : y0;
+  const int hx0 = (KIND == 0 || KIND == 4 || KIND == 5) ? x0 - 1 : (KIND == 1) ? 2 * x0 - 1 : (KIND == 2) ? x0 - 1 + px : x0;
 
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const int cg0 = chunk * KC;
@@ -429,8 +551,8 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
     }  // previous chunk's LDS reads are done
     // ---- stage: global -> (transform) -> LDS, U loads in flight per thread (HBM latency
     // is ~2 us under load; one load at a time would make this phase latency-bound)
-    if (KIND == 0 && p.init_x) {
-      stage_init_tile<false, RS>(p, tile, tile + NP * RS, cg0, img0, hy0, hx0, hth, htw, tq);
+    if ((KIND == 0 || KIND == 5) && p.init_x) {
+      stage_init_tile<false, RS, WINO>(p, tile, tile + NP * RS, cg0, img0, hy0, hx0, hth, htw, tq);
     } else
     {
       // Every VALU instruction here is paid for in MFMA time: the fp32 MFMA runs on the SIMD's
@@ -463,8 +585,11 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
           const unsigned off = (unsigned)((((cn << p.h_log) + cy) << p.w_log) + cx) << cs_log;
           v[u] = *reinterpret_cast<const float4*>(srcb + off);
           // zero padding / images past the batch stay exactly 0 and get no transform
+          if (WINO)  // four (row parity, column parity) planes per image
+            lofs = (((ii * 4 + (hy & 1) * 2 + (hx & 1)) * (hth >> 1) + (hy >> 1)) * (htw >> 1) + (hx >> 1)) * RS + c4 * 4;
           meta[u] = valid ? (lofs | (inb ? (((ii << p.c1_log) + coff + c4 * 4 + 1) << 16) : 0)) : -1;
-          pix += PPP; lofs += PPP * RS;
+          pix += PPP;
+          if (!WINO) lofs += PPP * RS;
           hx += p.ppp_r; hy += p.ppp_q;
           if (hx >= htw) { hx -= htw; ++hy; }
           while (hy >= hth) { hy -= hth; ++ii; }
@@ -533,6 +658,64 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
         }
       }
     }
+    if constexpr (WINO) {
+      // ---- Winograd F(2x2,3x3): sixteen [32 tiles x KC] x [KC x 64] products, one per point of the
+      // 4x4 transform domain; this wave owns points (i, 0..3).  Packed weights (U = G g G^T):
+      // [Cin/8][point][Cout/32][64 lanes][4].  Per channel group of 8: eight 16-byte LDS reads
+      // (rows rA, rB x 4 columns of the tile's input patch), 32 VALU (B^T d B on the fly), 32 MFMAs.
+      const int wv = __builtin_amdgcn_readfirstlane(tq >> 6);
+      const size_t gstride = (size_t)16 * nb32 * 256;
+      const float* wb5 = p.wp + ((size_t)chunk * NJ) * gstride + ((size_t)(wv * 4) * nb32 + blockIdx.y * 2) * 256 + (tq & 63) * 4;
+      float4 bq[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) bq[j * 2 + nb] = *reinterpret_cast<const float4*>(wb5 + (size_t)(j * nb32 + nb) * 256);
+      __syncthreads();
+      __builtin_amdgcn_s_setprio(0);
+      if (chunk == 0) {
+        DM_STAMP(1);
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+      }
+      float4 d[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const float4*>(tile + aoff[q]);
+#pragma unroll 1
+      for (int g = 0; g < NJ; ++g) {
+        float4 e[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          e[c].x = fmaf(wsg, d[4 + c].x, d[c].x); e[c].y = fmaf(wsg, d[4 + c].y, d[c].y);
+          e[c].z = fmaf(wsg, d[4 + c].z, d[c].z); e[c].w = fmaf(wsg, d[4 + c].w, d[c].w);
+        }
+        const int gn = (g + 1 < NJ) ? g + 1 : g;  // (clamped: the last prefetch re-reads valid data, unused)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const float4*>(tile + aoff[q] + gn * 8);
+        const float* wnext = wb5 + (size_t)gn * gstride;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4 v;
+          if (j == 0)      { v.x = e[0].x - e[2].x; v.y = e[0].y - e[2].y; v.z = e[0].z - e[2].z; v.w = e[0].w - e[2].w; }
+          else if (j == 1) { v.x = e[1].x + e[2].x; v.y = e[1].y + e[2].y; v.z = e[1].z + e[2].z; v.w = e[1].w + e[2].w; }
+          else if (j == 2) { v.x = e[2].x - e[1].x; v.y = e[2].y - e[1].y; v.z = e[2].z - e[1].z; v.w = e[2].w - e[1].w; }
+          else             { v.x = e[1].x - e[3].x; v.y = e[1].y - e[3].y; v.z = e[1].z - e[3].z; v.w = e[1].w - e[3].w; }
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const float4 b = bq[j * 2 + nb];
+            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, b.x, acc[j * 2 + nb], 0, 0, 0);
+            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, b.y, acc[j * 2 + nb], 0, 0, 0);
+            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, b.z, acc[j * 2 + nb], 0, 0, 0);
+            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, b.w, acc[j * 2 + nb], 0, 0, 0);
+            bq[j * 2 + nb] = *reinterpret_cast<const float4*>(wnext + (size_t)(j * nb32 + nb) * 256);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
     float4 bq[NJ];  // B fragments of tap 0: their L2 latency hides behind the barrier
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bq[j] = *reinterpret_cast<const float4*>(wbase + j * jstride);
@@ -589,7 +772,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       tx = ntx; ty = nty;
-      if (KIND == 4 && (tap & 3) == 3) {
+      if constexpr (KIND == 4) if ((tap & 3) == 3) {
         // one output parity is complete: store it (registers -> HBM; the input tile stays in
         // LDS for the next parity), emit its statistics partial, restart the accumulators
         par = tap >> 2; py = par >> 1; px = par & 1;
@@ -600,11 +783,15 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvArgs p) {
           for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
       }
     }
+    }  // !WINO
   }
 
   DM_STAMP(2);
   __builtin_amdgcn_s_setprio(2);
-  if (KIND != 4) {
+  if constexpr (WINO) {
+    __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
+    wino_epilogue(p, acc, smem, img0, tin, y0, x0, tq);
+  } else if constexpr (KIND != 4) {
     __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
     conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, (tq >> 7) & 1, (tq >> 6) & 1, tq & 63, (tq >> 5) & 1, tq, tq >> 6);
   }
@@ -646,6 +833,31 @@ __global__ void pack_conv_weight_kernel(int kind, const float* __restrict__ w, i
   const size_t src = (kind == 2) ? (((size_t)ci * cout + co) * ks + ky) * ks + kx
                                  : (((size_t)co * cin + ci) * ks + ky) * ks + kx;
   out[idx] = w[src];
+}
+
+// Winograd F(2x2,3x3) weight transform U = G g G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]) of a
+// Conv2d 3x3 weight w[cout][cin][3][3], packed in B-fragment order for conv_mfma_kernel<.,5,.>:
+//   out[cin/8][point = i*4+j][cout/32][lane][e] = U[i][j](cout = nb*32 + (lane&31), cin = 8*c8 + 4*(lane>>5) + e)
+__global__ void pack_wino_weight_kernel(const float* __restrict__ w, int cin, int cout, float* __restrict__ out, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  size_t r = idx;
+  const int e = r & 3; r >>= 2;
+  const int lane = r & 63; r >>= 6;
+  const int nb = r % (cout >> 5); r /= (cout >> 5);
+  const int pt = r & 15; r >>= 4;
+  const int c8 = (int)r;
+  const int i = pt >> 2, j = pt & 3;
+  const int co = nb * 32 + (lane & 31);
+  const int ci = c8 * 8 + 4 * (lane >> 5) + e;
+  const float* g = w + ((size_t)co * cin + ci) * 9;
+  float t[3];  // (G g)[i][kx]
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const float a = g[kx], b = g[3 + kx], c = g[6 + kx];
+    t[kx] = (i == 0) ? a : (i == 1) ? 0.5f * ((a + b) + c) : (i == 2) ? 0.5f * ((a - b) + c) : c;
+  }
+  out[idx] = (j == 0) ? t[0] : (j == 1) ? 0.5f * ((t[0] + t[1]) + t[2]) : (j == 2) ? 0.5f * ((t[0] - t[1]) + t[2]) : t[2];
 }
 
 // ------------------------------------------------------------------------------------------

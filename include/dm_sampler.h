@@ -144,7 +144,8 @@ enum {
   DM_K_TIME = 7,      /* time_embed_kernel                                              */
   DM_K_STEP = 8,      /* sampler_step_kernel                                (HBM-bound) */
   DM_K_ATTN = 9,      /* attention block: 1x1 qkv/proj convs, QK^T / PV GEMMs, softmax  */
-  DM_K_COUNT = 10
+  DM_K_WINO = 10,     /* conv_mfma_kernel<2,5,64>: 3x3 convs as Winograd F(2x2,3x3)  (MFMA) */
+  DM_K_COUNT = 11
 };
 int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int64_t* t_dev,
                     const float* coef_host, int B, int H, int W, void* workspace_dev,
@@ -154,7 +155,8 @@ int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int
 /* ---- single operators (NHWC), exported for the per-kernel parity tests ------------------
  * kind: 0 = Conv2d 3x3 pad 1 (model.py:42,45,47,99,102), 1 = Conv2d 4x4 stride 2 pad 1
  * (model.py:46), 2 = ConvTranspose2d 4x4 stride 2 pad 1 (model.py:43), 3 = Conv2d 1x1 (build-defined
- * attention block). */
+ * attention block), 5 = the same Conv2d 3x3 pad 1 as kind 0 evaluated as Winograd F(2x2,3x3) in fp32
+ * (H, W >= 8; what dm_unet_forward uses for its 3x3 layers from 8x8 up). */
 size_t dm_conv_packed_floats(int kind, int cin, int cout);
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev,
                         void* stream);

@@ -40,7 +40,7 @@ def run_conv(kind, x1, x2, w, b, tf=None, want_stats=False):
     B, c1, H, W = x1.shape
     c2 = 0 if x2 is None else x2.shape[1]
     cout = w.shape[1] if kind == 2 else w.shape[0]
-    OH, OW = (H, W) if kind == 0 else (H // 2, W // 2) if kind == 1 else (2 * H, 2 * W)
+    OH, OW = (H, W) if kind in (0, 5) else (H // 2, W // 2) if kind == 1 else (2 * H, 2 * W)
     wp = pack(kind, w)
     a1 = nhwc(x1).to(DEV)
     a2 = None if x2 is None else nhwc(x2).to(DEV)
@@ -91,6 +91,69 @@ def test_conv_plain(kind, B, H):
     rg = ref.reshape(B, 8, -1)
     assert (mean - rg.mean(2)).abs().max().item() <= 1e-5
     assert ((var - rg.var(2, unbiased=False)).abs() / rg.var(2, unbiased=False)).max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(3, 32, 32, 64, 64), (2, 16, 16, 64, 64), (5, 8, 8, 64, 64), (1, 8, 8, 64, 64),
+                                            (2, 64, 64, 256, 256), (2, 16, 32, 128, 64), (3, 8, 16, 64, 128)])
+def test_conv_winograd(B, H, W, cin, cout):
+    """kind 5: the 3x3 conv as Winograd F(2x2,3x3) (fp32 MFMA) against torch's direct conv + statistics."""
+    torch.manual_seed(B + H + cin)
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 3, 3) * (1.0 / (3.0 * cin ** 0.5))
+    b = torch.randn(cout)
+    y, st = run_conv(5, x, None, w, b, want_stats=True)
+    ref = F.conv2d(x, w, b, padding=1)
+    assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    P = st.shape[1]
+    cnt = H * W * (cout // 8) / P
+    mean, var = merge_stats(st, cnt)
+    rg = ref.reshape(B, 8, -1)
+    assert (mean - rg.mean(2)).abs().max().item() <= 1e-5
+    assert ((var - rg.var(2, unbiased=False)).abs() / rg.var(2, unbiased=False)).max().item() <= 1e-5
+
+
+def test_conv_winograd_concat_and_fused_transform():
+    torch.manual_seed(77)
+    B, H = 3, 16
+    x1, x2 = torch.randn(B, 64, H, H), torch.randn(B, 64, H, H)
+    w, b = torch.randn(64, 128, 3, 3) * 0.05, torch.randn(64)
+    y, _ = run_conv(5, x1, x2, w, b)
+    ref = F.conv2d(torch.cat([x1, x2], 1), w, b, padding=1)
+    assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    for Hh, per_img in ((32, False), (8, True)):
+        x0 = torch.randn(B, 64, Hh, Hh)
+        w0, b0 = torch.randn(64, 64, 3, 3) * 0.1, torch.randn(64) + 3.0
+        gamma, beta = torch.rand(64) + 0.5, torch.randn(64) * 0.1
+        temb = torch.randn(B if per_img else 1, 64)
+        w2, b2 = torch.randn(64, 64, 3, 3) * 0.05, torch.randn(64)
+        h_raw, st = run_conv(5, x0, None, w0, b0, want_stats=True)
+        P = st.shape[1]
+        tf = (st.to(DEV), P, Hh * Hh * 8 / P, gamma.to(DEV), beta.to(DEV), temb.to(DEV), 64 if per_img else 0)
+        y, _ = run_conv(5, h_raw, None, w2, b2, tf=tf)
+        hin = F.silu(F.group_norm(h_raw, 8, gamma, beta, eps=1e-5)) + temb[:, :, None, None]
+        ref = F.conv2d(hin, w2, b2, padding=1)
+        assert (y - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+    L = _lib.lib()
+    xx = torch.zeros(1, 4, 4, 64, device=DEV)
+    rc = L.dm_conv2d(5, _lib.ptr(xx), 64, None, 0, _lib.ptr(xx), _lib.ptr(xx), 64, None, 0, 0.0, None, None, None, 0,
+                     _lib.ptr(xx), None, 1, 4, 4, stream())
+    assert rc != 0 and b"Winograd" in L.dm_last_error()
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 5])
+def test_conv_large_batch_rows_match_small_batch(kind):
+    """The fp32 kernels are persistent (each workgroup walks several tiles once the grid exceeds the
+    resident slots): a batch large enough for several rounds must give, bit for bit, what the same
+    images give alone.  (Regression: the fused transposed conv kept its parity state across tiles.)"""
+    torch.manual_seed(3 + kind)
+    B, H = 448, 16
+    x = torch.randn(B, 64, H, H)
+    k = 3 if kind in (0, 5) else 4
+    w, b = torch.randn(64, 64, k, k) * 0.05, torch.randn(64)
+    y, st = run_conv(kind, x, None, w, b, want_stats=True)
+    for lo, hi in ((0, 32), (200, 232), (384, 448)):
+        y2, st2 = run_conv(kind, x[lo:hi].contiguous(), None, w, b, want_stats=True)
+        assert torch.equal(y[lo:hi], y2) and torch.equal(st[lo:hi], st2), (kind, lo)
 
 
 @pytest.mark.parametrize("H", [16, 4])

@@ -61,6 +61,18 @@ def test_forward_is_batch_independent(golden, model):
         assert torch.equal(model(x[lo:hi].contiguous(), t), full[lo:hi])
 
 
+def test_forward_large_batch_is_batch_independent(model):
+    """Same property at a batch that makes every persistent kernel walk several rounds of tiles."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((1024, 1, 32, 32), generator=g).to(DEV)
+    t = torch.tensor(500)
+    full = model(x, t)
+    for lo, hi in ((0, 8), (380, 400), (1000, 1024)):
+        assert torch.equal(model(x[lo:hi].contiguous(), t), full[lo:hi]), lo
+    ref = O.unet_forward({k: v.detach().cpu() for k, v in model.state_dict().items()}, x[1000:1024].cpu(), t)
+    assert (full[1000:1024].cpu() - ref).abs().max().item() <= EPS_TOL
+
+
 def test_ddim50_teacher_forced_and_free_running(golden, model):
     sched = d.DDPMScheduler()
     smp = d.DDIMSampler(sched, num_inference_steps=50, eta=0.0)
