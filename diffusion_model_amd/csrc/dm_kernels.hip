@@ -526,6 +526,7 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
   int tq = threadIdx.x;
   asm volatile("" : "+v"(tq));
   if (KIND == 4) { par = 0; py = 0; px = 0; }  // (advanced by the previous tile's K loop)
+  DM_STAMP_RAW(7);  // (diagnostic build) start of this tile: slots 7,1,2,3 bracket the LAST tile's phases
   const int img0 = (t / p.tiles_per_img) * p.ni;
   const int tin = t % p.tiles_per_img;
   const int y0 = (tin / p.tiles_x) << p.th_log;
