@@ -207,7 +207,11 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (fused_up ? 128 : 0) + init_f;
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
   if (lds_f < epi_f) lds_f = epi_f;
-  if (c.kind == 5 && lds_f < DM_WINO_EPI_FLOATS) lds_f = DM_WINO_EPI_FLOATS;
+  if (c.kind == 5) {
+    if (lds_f < DM_WINO_EPI_FLOATS) lds_f = DM_WINO_EPI_FLOATS;
+    lds_f += 208;  // staging descriptor table
+    if (np > 208) return fail("conv: Winograd tile has %zu halo pixels (> 208)", np);
+  }
   if (c.bf16) {
     lds_f = (np * (64 + 8) + 1) / 2 + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0) + init_f;
     const size_t e2 = (size_t)g.MT * 36 + 128;

@@ -342,6 +342,38 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
   }
 }
 
+// GroupNorm tables of one tile: scale = rstd*gamma, shift = beta - mean*scale, temb, per (image, channel),
+// from the producer's (mean, M2) partials merged in a fixed order (Chan et al.).
+__device__ __forceinline__ void gn_tables(const ConvArgs& p, int img0, int tq, float* s_scale, float* s_shift, float* s_temb) {
+  const int G = p.C1 / DM_GROUPS;
+  const int step = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
+  const float* te = p.temb ? p.temb + (size_t)step * p.temb_step_stride : nullptr;
+  for (int idx = tq; idx < p.ni * p.C1; idx += 256) {
+    const int i = idx >> p.c1_log, c = idx & (p.C1 - 1);
+    const int n = img0 + i;
+    float scale = 0.f, shift = 0.f, tv = 0.f;
+    if (n < p.B) {
+      const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c / G)) * 2;
+      float msum = 0.f;
+      for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
+      const float mean = msum / (float)p.pin;
+      float m2 = 0.f, dev = 0.f;
+      for (int q = 0; q < p.pin; ++q) {
+        const float d = st[q * DM_GROUPS * 2] - mean;
+        m2 += st[q * DM_GROUPS * 2 + 1];
+        dev += d * d;
+      }
+      const float var = (m2 + p.cnt_in * dev) / (p.cnt_in * (float)p.pin);
+      scale = rsqrtf(var + DM_GN_EPS) * p.gamma[c];
+      shift = p.beta[c] - mean * scale;
+      if (te) tv = te[(size_t)n * p.temb_stride + c];
+    }
+    s_scale[idx] = scale;
+    s_shift[idx] = shift;
+    s_temb[idx] = tv;
+  }
+}
+
 // Epilogue of the Winograd kernel (KIND 5).  Wave i holds M[i][j] (j = 0..3) of 32 tiles x 64 channels:
 // the row half of the output transform (T[i][b] = sum_j M[i][j] A^T[b][j]) happens in registers, the
 // column half (Y[a][b] = sum_i A^T[a][i] T[i][b]) needs all four waves and goes through LDS.  Then, with
@@ -470,7 +502,8 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
 
   // ---- LDS carve: [scale ni*C1][shift ni*C1][temb ni*C1][tile NP*RS]
   const bool tf = p.stats_in != nullptr;
-  float* s_scale = smem;
+  float* smem_b = smem + (WINO ? 208 : 0);  // (KIND 5: the descriptor table sits in front)
+  float* s_scale = smem_b;
   float* s_shift = s_scale + (tf ? p.ni * p.C1 : 0);
   float* s_temb = s_shift + (tf ? p.ni * p.C1 : 0);
   float* tile = s_temb + (tf ? p.ni * p.C1 : 0);
@@ -489,7 +522,8 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
   // KIND 5 (Winograd): wave i owns the transform-domain points (i, 0..3) of the 32 2x2-pixel
   // tiles, for both 32-channel halves: acc[j*2 + nb].  aoff: the lane's eight LDS reads per channel
   // group — rows rA and rB of its tile's 4x4 input patch (B^T row i has two non-zeros), 4 columns.
-  int aoff[WINO ? 8 : 1];
+  int albase = 0;         // lane part of the A-read offsets (floats)
+  int auo[WINO ? 8 : 1];  // wave-uniform part (scalar registers)
   float wsg = 0.f;
   if constexpr (WINO) {
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -501,11 +535,11 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
     const int txw = tl & ((tw >> 1) - 1);
     const int tyw = (tl >> (p.tw_log - 1)) & ((th >> 1) - 1);
     const int iw = tl >> (p.tw_log + p.th_log - 2);
-    const int L0 = (iw * 4 * PH + tyw) * PW + txw;
+    albase = ((iw * 4 * PH + tyw) * PW + txw) * RS + 4 * h;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int r = (q < 4) ? rA : rB, sc = q & 3;
-      aoff[q] = (L0 + (((r & 1) * 2 + (sc & 1)) * PH + (r >> 1)) * PW + (sc >> 1)) * RS + 4 * h;
+      auo[q] = __builtin_amdgcn_readfirstlane(((((r & 1) * 2 + (sc & 1)) * PH + (r >> 1)) * PW + (sc >> 1)) * RS);
     }
   }
   f32x16 acc[WINO ? 8 : MB];  // zeroed after the first chunk is staged (keeps staging's register peak low)
@@ -516,6 +550,26 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
   const int nchunks = Cin / KC;
   constexpr int V = KC / 4;
   constexpr int U = 12;  // global loads in flight per thread while staging (one batch covers a tile)
+  // KIND 5: staging descriptors, computed ONCE per workgroup (not per tile) into a 208-entry LDS table:
+  // halo pixel q of the tile -> LDS float offset | hx << 16 | hy << 22 | image << 28, bit 31 = past the
+  // tile.  Address math beside a streaming fp32-MFMA wave costs about an MFMA slot per instruction, so
+  // what does not depend on the tile is looked up (LDS reads are not VALU) and the per-tile part is ~10
+  // instructions per load.  (Kept in LDS, not registers: 13 more live registers spill beside 128 accumulators.)
+  constexpr int UW = 13;
+  int* ptab = reinterpret_cast<int*>(smem);
+  if constexpr (WINO) {
+    if (tid < 16 * UW) {
+      const int pix = tid;
+      const int PH = hth >> 1, PW = htw >> 1;
+      const int r = __umulhi((unsigned)pix, p.mg_htw);
+      const int hx = pix - r * htw;
+      const int ii = __umulhi((unsigned)r, p.mg_hth);
+      const int hy = r - ii * hth;
+      const int lofs = (((ii * 4 + (hy & 1) * 2 + (hx & 1)) * PH + (hy >> 1)) * PW + (hx >> 1)) * RS;
+      ptab[tid] = (pix < NP) ? (lofs | (hx << 16) | (hy << 22) | (ii << 28)) : (int)0x80000000;
+    }
+    __syncthreads();
+  }
 
   // Persistent workgroups: the grid is at most 3 per CU and each workgroup walks tiles
   // t, t + gridDim.x, ...  (a finished workgroup's slot otherwise stays empty for 2-16 k cycles
@@ -554,6 +608,59 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
     // is ~2 us under load; one load at a time would make this phase latency-bound)
     if ((KIND == 0 || KIND == 5) && p.init_x) {
       stage_init_tile<false, RS, WINO>(p, tile, tile + NP * RS, cg0, img0, hy0, hx0, hth, htw, tq);
+    } else if constexpr (WINO) {
+      const int c4 = tq & 15;
+      const int cs_log = from2 ? p.c2_log : p.c1_log;
+      const float* srcb = src + ((size_t)img0 << (p.h_log + p.w_log + cs_log)) + coff + c4 * 4;
+      const int imax = p.B - 1 - img0;  // images past the batch: clamped address, zero fill
+      const int hw1 = (p.H << p.w_log) - 1;
+      float4 v[UW];
+      int pk[UW];
+      const int p0 = tq >> 4;
+#pragma unroll
+      for (int u = 0; u < UW; ++u) pk[u] = ptab[p0 + 16 * u] + c4 * 4;
+      unsigned inbm = 0;  // bit u: pixel u is inside the image (else zero padding / past the batch)
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        const int k = pk[u];
+        const int hxu = (k >> 16) & 63, hyu = (k >> 22) & 63, iu = (k >> 28) & 7;
+        const int iy = hy0 + hyu, ix = hx0 + hxu;
+        const bool inb = k >= 0 && iu <= imax && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        // unconditional load from a clamped (always valid) address; padding is a select afterwards
+        const int lin = min(max((iy << p.w_log) + ix, 0), hw1);
+        const unsigned off = (unsigned)((min(iu, imax) << (p.h_log + p.w_log)) + lin) << cs_log;
+        v[u] = *reinterpret_cast<const float4*>(srcb + off);
+        inbm |= inb ? (1u << u) : 0u;
+      }
+      if (tf && chunk == 0) {
+        gn_tables(p, img0, tq, s_scale, s_shift, s_temb);  // while the tile loads are in flight
+        __syncthreads();
+      }
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        const int k = pk[u];
+        if (k >= 0) {
+          float4 w = v[u];
+          if (tf) {
+            // table entries come from LDS every time (three 16-byte reads, no VALU): holding them in
+            // 12 registers across the loop spills beside the 128 accumulators
+            const int tofs = (((k >> 28) & 7) << p.c1_log) + coff + c4 * 4;
+            const float4 sc = *reinterpret_cast<const float4*>(s_scale + tofs);
+            const float4 sh = *reinterpret_cast<const float4*>(s_shift + tofs);
+            const float4 te = *reinterpret_cast<const float4*>(s_temb + tofs);
+            w.x = fmaf(w.x, sc.x, sh.x); w.y = fmaf(w.y, sc.y, sh.y);
+            w.z = fmaf(w.z, sc.z, sh.z); w.w = fmaf(w.w, sc.w, sh.w);
+            if (p.tf_silu) {
+              w.x = dm_silu_add(w.x, te.x); w.y = dm_silu_add(w.y, te.y);
+              w.z = dm_silu_add(w.z, te.z); w.w = dm_silu_add(w.w, te.w);
+            } else {
+              w.x += te.x; w.y += te.y; w.z += te.z; w.w += te.w;
+            }
+          }
+          if (!((inbm >> u) & 1)) w = make_float4(0.f, 0.f, 0.f, 0.f);  // padding stays exactly 0
+          *reinterpret_cast<float4*>(tile + (k & 0xffff)) = w;
+        }
+      }
     } else
     {
       // Every VALU instruction here is paid for in MFMA time: the fp32 MFMA runs on the SIMD's
@@ -598,33 +705,7 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
         if (tf && chunk == 0 && base == 0) {
           // GroupNorm tables (scale, shift = beta - mean*scale, temb per (image, channel)),
           // computed while the first batch of tile loads is in flight
-          const int G = p.C1 / DM_GROUPS;
-          const int step = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
-          const float* te = p.temb ? p.temb + (size_t)step * p.temb_step_stride : nullptr;
-          for (int idx = tq; idx < p.ni * p.C1; idx += 256) {
-            const int i = idx >> p.c1_log, c = idx & (p.C1 - 1);
-            const int n = img0 + i;
-            float scale = 0.f, shift = 0.f, tv = 0.f;
-            if (n < p.B) {
-              const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c / G)) * 2;
-              float msum = 0.f;
-              for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
-              const float mean = msum / (float)p.pin;
-              float m2 = 0.f, dev = 0.f;
-              for (int q = 0; q < p.pin; ++q) {
-                const float d = st[q * DM_GROUPS * 2] - mean;
-                m2 += st[q * DM_GROUPS * 2 + 1];
-                dev += d * d;
-              }
-              const float var = (m2 + p.cnt_in * dev) / (p.cnt_in * (float)p.pin);
-              scale = rsqrtf(var + DM_GN_EPS) * p.gamma[c];
-              shift = p.beta[c] - mean * scale;
-              if (te) tv = te[(size_t)n * p.temb_stride + c];
-            }
-            s_scale[idx] = scale;
-            s_shift[idx] = shift;
-            s_temb[idx] = tv;
-          }
+          gn_tables(p, img0, tq, s_scale, s_shift, s_temb);
           __syncthreads();  // uniform condition
         }
         float4 hsc, hsh;  // with one image per tile the thread's table entries never change
@@ -666,12 +747,14 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
       // (rows rA, rB x 4 columns of the tile's input patch), 32 VALU (B^T d B on the fly), 32 MFMAs.
       const int wv = __builtin_amdgcn_readfirstlane(tq >> 6);
       const size_t gstride = (size_t)16 * nb32 * 256;
-      const float* wb5 = p.wp + ((size_t)chunk * NJ) * gstride + ((size_t)(wv * 4) * nb32 + blockIdx.y * 2) * 256 + (tq & 63) * 4;
+      // wave-uniform fragment pointers (scalar registers) + one 32-bit lane offset: saddr-form loads
+      const float* wu5 = p.wp + ((size_t)chunk * NJ) * gstride + ((size_t)(wv * 4) * nb32 + blockIdx.y * 2) * 256;
+      const unsigned lane16 = (unsigned)(tq & 63) * 16u;  // byte offset: (uniform base) + zext(32-bit) selects the saddr form
       float4 bq[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) bq[j * 2 + nb] = *reinterpret_cast<const float4*>(wb5 + (size_t)(j * nb32 + nb) * 256);
+        for (int nb = 0; nb < 2; ++nb) bq[j * 2 + nb] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wu5 + (size_t)(j * nb32 + nb) * 256) + lane16);
       __syncthreads();
       __builtin_amdgcn_s_setprio(0);
       if (chunk == 0) {
@@ -681,37 +764,43 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
       }
-      float4 d[8];
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 sg2 = {wsg, wsg};
+      f32x2 dl[8], dh[8];  // .xy / .zw halves of the eight 16-byte reads
 #pragma unroll
-      for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const float4*>(tile + aoff[q]);
-#pragma unroll 1
-      for (int g = 0; g < NJ; ++g) {
-        float4 e[4];
+      for (int q = 0; q < 8; ++q) {
+        const float4 t4 = *reinterpret_cast<const float4*>(tile + albase + auo[q]);
+        dl[q] = f32x2{t4.x, t4.y}; dh[q] = f32x2{t4.z, t4.w};
+      }
+#pragma unroll
+      for (int g = 0; g < NJ; ++g) {  // fully unrolled: LDS/global offsets become immediates, no register rotation
+        f32x2 el[4], eh[4];  // e[c] = d[rA][c] +- d[rB][c]  (B^T d, this wave's row)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          e[c].x = fmaf(wsg, d[4 + c].x, d[c].x); e[c].y = fmaf(wsg, d[4 + c].y, d[c].y);
-          e[c].z = fmaf(wsg, d[4 + c].z, d[c].z); e[c].w = fmaf(wsg, d[4 + c].w, d[c].w);
+          el[c] = __builtin_elementwise_fma(sg2, dl[4 + c], dl[c]);
+          eh[c] = __builtin_elementwise_fma(sg2, dh[4 + c], dh[c]);
         }
         const int gn = (g + 1 < NJ) ? g + 1 : g;  // (clamped: the last prefetch re-reads valid data, unused)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const float4*>(tile + aoff[q] + gn * 8);
-        const float* wnext = wb5 + (size_t)gn * gstride;
+        for (int q = 0; q < 8; ++q) {
+          const float4 t4 = *reinterpret_cast<const float4*>(tile + albase + auo[q] + gn * 8);
+          dl[q] = f32x2{t4.x, t4.y}; dh[q] = f32x2{t4.z, t4.w};
+        }
+        const float* wnext = wu5 + (size_t)gn * gstride;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          float4 v;
-          if (j == 0)      { v.x = e[0].x - e[2].x; v.y = e[0].y - e[2].y; v.z = e[0].z - e[2].z; v.w = e[0].w - e[2].w; }
-          else if (j == 1) { v.x = e[1].x + e[2].x; v.y = e[1].y + e[2].y; v.z = e[1].z + e[2].z; v.w = e[1].w + e[2].w; }
-          else if (j == 2) { v.x = e[2].x - e[1].x; v.y = e[2].y - e[1].y; v.z = e[2].z - e[1].z; v.w = e[2].w - e[1].w; }
-          else             { v.x = e[1].x - e[3].x; v.y = e[1].y - e[3].y; v.z = e[1].z - e[3].z; v.w = e[1].w - e[3].w; }
+          // (B^T d B)[i][j]: columns combine as e0-e2, e1+e2, e2-e1, e1-e3
+          const f32x2 vl = (j == 0) ? el[0] - el[2] : (j == 1) ? el[1] + el[2] : (j == 2) ? el[2] - el[1] : el[1] - el[3];
+          const f32x2 vh = (j == 0) ? eh[0] - eh[2] : (j == 1) ? eh[1] + eh[2] : (j == 2) ? eh[2] - eh[1] : eh[1] - eh[3];
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
             const float4 b = bq[j * 2 + nb];
-            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, b.x, acc[j * 2 + nb], 0, 0, 0);
-            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, b.y, acc[j * 2 + nb], 0, 0, 0);
-            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, b.z, acc[j * 2 + nb], 0, 0, 0);
-            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, b.w, acc[j * 2 + nb], 0, 0, 0);
-            bq[j * 2 + nb] = *reinterpret_cast<const float4*>(wnext + (size_t)(j * nb32 + nb) * 256);
+            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl.x, b.x, acc[j * 2 + nb], 0, 0, 0);
+            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl.y, b.y, acc[j * 2 + nb], 0, 0, 0);
+            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh.x, b.z, acc[j * 2 + nb], 0, 0, 0);
+            acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh.y, b.w, acc[j * 2 + nb], 0, 0, 0);
+            bq[j * 2 + nb] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wnext + (size_t)(j * nb32 + nb) * 256) + lane16);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -791,7 +880,7 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
   __builtin_amdgcn_s_setprio(2);
   if constexpr (WINO) {
     __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
-    wino_epilogue(p, acc, smem, img0, tin, y0, x0, tq);
+    wino_epilogue(p, acc, smem_b, img0, tin, y0, x0, tq);
   } else if constexpr (KIND != 4) {
     __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
     conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, (tq >> 7) & 1, (tq >> 6) & 1, tq & 63, (tq >> 5) & 1, tq, tq >> 6);
