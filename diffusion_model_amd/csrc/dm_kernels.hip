@@ -999,15 +999,17 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
                                                          int pin, float cnt_in, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                         int B, int HW, int C, int Cout) {
+                                                         int B, int HW, int C, int Cout, int slabs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_mean = smem;           // [C]
   float* s_scale = s_mean + C;    // [C]
   float* s_beta = s_scale + C;    // [C]
   float* s_w = s_beta + C;        // [Cout][C]
-  const int blocks_img = HW / 64;
+  // a block handles `slabs` 64-pixel slabs of one image: the table prologue (dependent global loads)
+  // is paid once per 16*slabs KiB streamed instead of once per 16 KiB
+  const int blocks_img = HW / (64 * slabs);
   const int n = blockIdx.x / blocks_img;
-  const int pix0 = (blockIdx.x % blocks_img) * 64;
+  const int pixb = (blockIdx.x % blocks_img) * 64 * slabs;
   const int G = C / DM_GROUPS;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float* st = stats + ((size_t)n * pin * DM_GROUPS + c / G) * 2;
@@ -1031,6 +1033,8 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
   const int LP = V < 64 ? V : 64;      // lanes per pixel (power of two)
   const int ppp = 256 / LP;            // pixels per pass
   const int q = threadIdx.x % LP;
+  for (int sl = 0; sl < slabs; ++sl) {
+  const int pix0 = pixb + sl * 64;
   for (int pp = threadIdx.x / LP; pp < 64; pp += ppp) {
     const float* up = u + ((size_t)n * HW + pix0 + pp) * C;
     float part[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1061,6 +1065,7 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
       }
     }
   }
+  }  // slabs
 }
 
 // ------------------------------------------------------------------------------------------
