@@ -75,12 +75,14 @@ struct ConvGeo {
 // independent of the batch size and of how a batch is sharded over GPUs.
 ConvGeo conv_geo(int kind, int H, int W, int Cout) {
   ConvGeo g;
+  const bool down128 = kind == 6;  // kind 6: the 4x4 stride-2 conv (kind 1) on 128-pixel tiles, 16-channel K chunks
+  if (down128) kind = 1;
   g.Hb = (kind == 1) ? H / 2 : H;
   g.Wb = (kind == 1) ? W / 2 : W;
   g.OH = (kind == 1) ? H / 2 : (kind == 2) ? 2 * H : H;
   g.OW = (kind == 1) ? W / 2 : (kind == 2) ? 2 * W : W;
   const int npix = g.Hb * g.Wb;
-  g.MT = (kind == 1) ? 64 : (kind == 5 || npix >= 256) ? 128 : 64;  // kind 5 (Winograd): always 32 2x2-pixel tiles
+  g.MT = (kind == 1) ? (down128 ? 128 : 64) : (kind == 5 || npix >= 256) ? 128 : 64;  // kind 5 (Winograd): always 32 2x2-pixel tiles
   int tw = g.Wb < ((kind == 1) ? 8 : 16) ? g.Wb : ((kind == 1) ? 8 : 16);
   int th = g.Hb < g.MT / tw ? g.Hb : g.MT / tw;
   g.ni = g.MT / (th * tw);
@@ -160,14 +162,15 @@ int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
 
 int launch_conv(const ConvCall& c, hipStream_t s) {
   const int cin = c.c1 + c.c2;
-  if (c.kind < 0 || (c.kind > 3 && c.kind != 5)) return fail("conv: unknown kind %d", c.kind);
+  if (c.kind < 0 || (c.kind > 3 && c.kind != 5 && c.kind != 6)) return fail("conv: unknown kind %d", c.kind);
+  if (c.kind == 6 && (c.bf16 || (c.H / 2) * (c.W / 2) < 128)) return fail("conv: the 128-pixel-tile stride-2 variant is fp32, for outputs of >= 128 pixels");
   if (c.kind == 5 && (c.bf16 || c.res || c.H < 8 || c.W < 8))
     return fail("conv: the Winograd 3x3 path is fp32, without residual, for H,W >= 8 (got %dx%d)", c.H, c.W);
   if (c.c1 % 64 || c.c2 % 64 || c.cout % 64) return fail("conv: channel counts must be multiples of 64 (got %d+%d -> %d)", c.c1, c.c2, c.cout);
   if (c.cout != 64 && c.cout != 128 && c.cout != 256 && c.cout != 512 && c.stats_out)
     return fail("conv: GroupNorm(8) statistics need Cout in {64,128,256,512} (got %d)", c.cout);
   if (!is_pow2(c.H) || !is_pow2(c.W)) return fail("conv: spatial dims must be powers of two (got %dx%d)", c.H, c.W);
-  if (c.kind == 1 && (c.H < 2 || c.W < 2)) return fail("conv: stride-2 conv needs H,W >= 2");
+  if ((c.kind == 1 || c.kind == 6) && (c.H < 2 || c.W < 2)) return fail("conv: stride-2 conv needs H,W >= 2");
   if (c.stats_in && c.c2) return fail("conv: input transform and channel concat are exclusive");
   if (c.B <= 0) return fail("conv: empty batch");
   ConvGeo g = conv_geo(c.kind, c.H, c.W, c.cout);
@@ -193,7 +196,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   a.h_log = ilog2(c.H); a.w_log = ilog2(c.W); a.c1_log = ilog2(c.c1); a.c2_log = c.c2 ? ilog2(c.c2) : 0;
   a.cout_log = is_pow2(c.cout) ? ilog2(c.cout) : -1;
   {
-    const int ppp = (c.bf16 || c.kind == 1) ? 32 : 16;  // 256 threads / (16-byte loads per pixel per chunk)
+    const int ppp = c.kind == 6 ? 64 : (c.bf16 || c.kind == 1) ? 32 : 16;  // 256 threads / (16-byte loads per pixel per chunk)
     a.ppp_q = ppp / g.htw; a.ppp_r = ppp % g.htw;
   }
   a.init_x = c.init_x; a.init_w = c.init_w; a.init_b = c.init_b; a.init_cin = c.init_cin;
@@ -202,7 +205,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
 #ifdef DM_STAMPS
   a.stamps = g_stamps;
 #endif
-  const int kc = (c.kind == 1) ? 32 : 64;
+  const int kc = (c.kind == 6) ? 16 : (c.kind == 1) ? 32 : 64;
   const size_t np = (size_t)g.ni * g.hth * g.htw;
   size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (fused_up ? 128 : 0) + init_f;
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
@@ -233,6 +236,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
     return launch_conv_bf16_t<1, 1>(a, grid, lds, s);
   }
   if (c.kind == 5) return launch_conv_t<2, 5, 64>(a, grid, lds, s);
+  if (c.kind == 6) return launch_conv_t<2, 1, 16>(a, grid, lds, s);
   if (fused_up) return g.MT == 128 ? launch_conv_t<2, 4, 64>(a, grid, lds, s) : launch_conv_t<1, 4, 64>(a, grid, lds, s);
   (void)cin;
   if (c.kind == 0) return g.MT == 128 ? launch_conv_t<2, 0, 64>(a, grid, lds, s) : launch_conv_t<1, 0, 64>(a, grid, lds, s);
@@ -242,11 +246,13 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
 }
 
 size_t conv_packed_floats(int kind, int cin, int cout) {
+  if (kind == 6) kind = 1;  // same packed weights
   const int taps = kind == 0 ? 9 : kind == 3 ? 1 : 16;  // KIND 2: 4 parities x 4 taps; KIND 5: 16 transform points
   return (size_t)taps * cin * cout;
 }
 
 int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream_t s, int bf16 = 0) {
+  if (kind == 6) kind = 1;
   if (cin % 16 || cout % 32) return fail("pack_conv: cin %% 16 / cout %% 32");
   const size_t total = conv_packed_floats(kind, cin, cout);
   if (bf16) {
@@ -450,14 +456,15 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     c.temb = heads + (size_t)k * C; c.temb_stride = heads_img_stride; c.temb_step_stride = heads_step_stride;
     c.step_ptr = step_ptr; c.step_off = step_off;
     if (launch_conv(c, s)) return 1;
-    base(up ? 2 : 1, w.T2, C, nullptr, 0, o.tr, o.trb, out, out_stats, h, ww);
+    const int kdn = (!m->bf16 && (h / 2) * (ww / 2) >= 256) ? 6 : 1;  // stride-2 conv: 128-pixel tiles from 16x16 outputs up
+    base(up ? 2 : kdn, w.T2, C, nullptr, 0, o.tr, o.trb, out, out_stats, h, ww);
     with_tf(w.SB, kd, h, ww, o.g2, o.b2);
     return launch_conv(c, s);
   };
   if (block(0, w.A0, nullptr, H, W, false, w.D1, nullptr)) return 1;
   if (block(1, w.D1, nullptr, H / 2, W / 2, false, w.D2, m->attn ? w.SA : nullptr)) return 1;
   if (m->attn) {
-    const ConvGeo pg = conv_geo(1, H / 2, W / 2, C);
+    const ConvGeo pg = conv_geo((!m->bf16 && (H / 4) * (W / 4) >= 256) ? 6 : 1, H / 2, W / 2, C);  // down2.transform
     if (attention_block(m, P, 0, w.D2, w.SA, pg.pout, pg.cnt_out, w, B, H / 4, W / 4, H, W, s)) return 1;
   }
   if (block(2, w.D2, nullptr, H / 4, W / 4, false, w.D3, nullptr)) return 1;
@@ -480,10 +487,12 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     const ConvGeo pg = conv_geo(2, H / 2, W / 2, C);
     const size_t lds = (size_t)(3 * C + m->Cout * C) * sizeof(float);
     ProfScope ps(DM_K_FINAL, s, 2.0 * B * H * W * C * m->Cout, 4.0 * B * H * W * (C + m->Cout));
-    if (m->bf16)
-      hipLaunchKernelGGL(final_conv_bf16_kernel, dim3((unsigned)(B * (H * W / 64))), dim3(256), lds, s,
+    if (m->bf16) {
+      const int slabs = (H * W / 64) >= 8 ? 8 : (H * W / 64);
+      hipLaunchKernelGGL(final_conv_bf16_kernel, dim3((unsigned)(B * (H * W / 64 / slabs))), dim3(256), lds, s,
                          reinterpret_cast<const bf16_t*>(w.A0), w.SA, pg.pout, pg.cnt_out, P + m->o_fg, P + m->o_fb,
-                         P + m->o_fw, P + m->o_fwb, eps, B, H * W, C, m->Cout);
+                         P + m->o_fw, P + m->o_fwb, eps, B, H * W, C, m->Cout, slabs);
+    }
     else
     {
       const int slabs = (H * W / 64) >= 8 ? 8 : (H * W / 64);  // measured at 32x32, B=1024: 1 -> 96 us, 8 -> 62 us, 16 -> 85 us
@@ -841,12 +850,12 @@ size_t dm_conv_packed_floats(int kind, int cin, int cout) { return conv_packed_f
 
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev, void* stream) {
   if (!w_dev || !packed_dev) return fail("dm_pack_conv_weight: null argument");
-  if (kind < 0 || (kind > 3 && kind != 5)) return fail("unknown conv kind %d", kind);
+  if (kind < 0 || (kind > 3 && kind != 5 && kind != 6)) return fail("unknown conv kind %d", kind);
   return pack_conv(kind, w_dev, cin, cout, packed_dev, (hipStream_t)stream);
 }
 
 int dm_conv_stats_partials(int kind, int H, int W) {
-  if (kind < 0 || (kind > 3 && kind != 5) || !is_pow2(H) || !is_pow2(W)) return 0;
+  if (kind < 0 || (kind > 3 && kind != 5 && kind != 6) || !is_pow2(H) || !is_pow2(W)) return 0;
   return conv_geo(kind, H, W, 64).pout;
 }
 

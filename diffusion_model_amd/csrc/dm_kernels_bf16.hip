@@ -274,15 +274,15 @@ __global__ __launch_bounds__(256) void final_conv_bf16_kernel(const bf16_t* __re
                                                               int pin, float cnt_in, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ out,
-                                                              int B, int HW, int C, int Cout) {
+                                                              int B, int HW, int C, int Cout, int slabs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_mean = smem;
   float* s_scale = s_mean + C;
   float* s_beta = s_scale + C;
   float* s_w = s_beta + C;
-  const int blocks_img = HW / 64;
+  const int blocks_img = HW / (64 * slabs);  // `slabs` 64-pixel slabs per block (see final_conv_kernel)
   const int n = blockIdx.x / blocks_img;
-  const int pix0 = (blockIdx.x % blocks_img) * 64;
+  const int pixb = (blockIdx.x % blocks_img) * 64 * slabs;
   const int G = C / DM_GROUPS;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float* st = stats + ((size_t)n * pin * DM_GROUPS + c / G) * 2;
@@ -306,6 +306,8 @@ __global__ __launch_bounds__(256) void final_conv_bf16_kernel(const bf16_t* __re
   const int LP = V < 64 ? V : 64;
   const int ppp = 256 / LP;
   const int q = threadIdx.x % LP;
+  for (int sl = 0; sl < slabs; ++sl) {
+  const int pix0 = pixb + sl * 64;
   for (int pp = threadIdx.x / LP; pp < 64; pp += ppp) {
     const bf16_t* up = u + ((size_t)n * HW + pix0 + pp) * C;
     float part[4] = {0.f, 0.f, 0.f, 0.f};
@@ -331,4 +333,5 @@ __global__ __launch_bounds__(256) void final_conv_bf16_kernel(const bf16_t* __re
         if (q == 0) out[((size_t)n * Cout + co) * HW + pix0 + pp] = sm + bias[co];
       }
   }
+  }  // slabs
 }

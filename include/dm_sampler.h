@@ -156,7 +156,9 @@ int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int
  * kind: 0 = Conv2d 3x3 pad 1 (model.py:42,45,47,99,102), 1 = Conv2d 4x4 stride 2 pad 1
  * (model.py:46), 2 = ConvTranspose2d 4x4 stride 2 pad 1 (model.py:43), 3 = Conv2d 1x1 (build-defined
  * attention block), 5 = the same Conv2d 3x3 pad 1 as kind 0 evaluated as Winograd F(2x2,3x3) in fp32
- * (H, W >= 8; what dm_unet_forward uses for its 3x3 layers from 8x8 up). */
+ * (H, W >= 8; what dm_unet_forward uses for its 3x3 layers from 8x8 up), 6 = the Conv2d 4x4 stride 2
+ * of kind 1 on 128-pixel tiles with 16-channel K chunks (fp32, outputs of >= 128 pixels; same packed
+ * weights as kind 1; what dm_unet_forward uses from 16x16 outputs up). */
 size_t dm_conv_packed_floats(int kind, int cin, int cout);
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev,
                         void* stream);

@@ -40,7 +40,7 @@ def run_conv(kind, x1, x2, w, b, tf=None, want_stats=False):
     B, c1, H, W = x1.shape
     c2 = 0 if x2 is None else x2.shape[1]
     cout = w.shape[1] if kind == 2 else w.shape[0]
-    OH, OW = (H, W) if kind in (0, 5) else (H // 2, W // 2) if kind == 1 else (2 * H, 2 * W)
+    OH, OW = (H, W) if kind in (0, 5) else (H // 2, W // 2) if kind in (1, 6) else (2 * H, 2 * W)
     wp = pack(kind, w)
     a1 = nhwc(x1).to(DEV)
     a2 = None if x2 is None else nhwc(x2).to(DEV)
@@ -110,6 +110,31 @@ def test_conv_winograd(B, H, W, cin, cout):
     rg = ref.reshape(B, 8, -1)
     assert (mean - rg.mean(2)).abs().max().item() <= 1e-5
     assert ((var - rg.var(2, unbiased=False)).abs() / rg.var(2, unbiased=False)).max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("B,H", [(3, 32), (2, 64), (130, 32)])
+def test_conv_down_128_pixel_tiles(B, H):
+    """kind 6: the 4x4 stride-2 conv on 128-pixel tiles with 16-channel K chunks == kind 1's result."""
+    torch.manual_seed(B + H)
+    x = torch.randn(B, 64, H, H)
+    w, b = torch.randn(64, 64, 4, 4) * 0.05, torch.randn(64)
+    y, st = run_conv(6, x, None, w, b, want_stats=True)
+    ref = F.conv2d(x, w, b, stride=2, padding=1)
+    assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    P = st.shape[1]
+    mean, var = merge_stats(st, (H // 2) ** 2 * 8 / P)
+    rg = ref.reshape(B, 8, -1)
+    assert (mean - rg.mean(2)).abs().max().item() <= 1e-5
+    assert ((var - rg.var(2, unbiased=False)).abs() / rg.var(2, unbiased=False)).max().item() <= 1e-5
+    # with the fused input transform
+    gamma, beta, temb = torch.rand(64) + 0.5, torch.randn(64) * 0.1, torch.randn(1, 64)
+    h_raw, st0 = run_conv(5, x, None, torch.randn(64, 64, 3, 3) * 0.1, b + 3.0, want_stats=True)
+    P0 = st0.shape[1]
+    tf = (st0.to(DEV), P0, H * H * 8 / P0, gamma.to(DEV), beta.to(DEV), temb.to(DEV), 0)
+    y2, _ = run_conv(6, h_raw, None, w, b, tf=tf)
+    hin = F.silu(F.group_norm(h_raw, 8, gamma, beta, eps=1e-5)) + temb[:, :, None, None]
+    ref2 = F.conv2d(hin, w, b, stride=2, padding=1)
+    assert (y2 - ref2).abs().max().item() <= 3e-5 * max(1.0, ref2.abs().max().item())
 
 
 def test_conv_winograd_concat_and_fused_transform():
