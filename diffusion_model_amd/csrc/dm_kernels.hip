@@ -34,6 +34,10 @@ __device__ __forceinline__ float dm_silu_add(float v, float t) {
 //   KIND 3: Conv2d 1x1 (attention qkv / proj; optional residual add)
 //   KIND 4: ConvTranspose2d 4x4 s2 p1 with all four output parities computed from ONE staged
 //           tile (Cin == KC only): the input is read and transformed once instead of four times
+//   KIND 5: Conv2d 3x3 s1 p1 as Winograd F(2x2,3x3): 16 transform-domain products instead of 36
+//           multiplies per 2x2 outputs, input transform on the fly from the raw LDS tile, output
+//           transform in registers + one LDS exchange (see wino_epilogue); H, W >= 8
+//   (<2,1,16>: KIND 1 on 128-pixel tiles with 16-channel K chunks, host-side "kind 6")
 // GEMM view: M = output pixels (tile of MT = 64*MB pixels per workgroup), N = 64 output
 // channels per workgroup (blockIdx.y), K = taps x input channels, walked as
 // [channel chunk of KC][tap][8 channels].
