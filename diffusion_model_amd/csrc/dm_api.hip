@@ -195,6 +195,9 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
     return fail("conv: input channel counts must be powers of two (got %d+%d)", c.c1, c.c2);
   a.h_log = ilog2(c.H); a.w_log = ilog2(c.W); a.c1_log = ilog2(c.c1); a.c2_log = c.c2 ? ilog2(c.c2) : 0;
   a.cout_log = is_pow2(c.cout) ? ilog2(c.cout) : -1;
+  a.tpi_log = ilog2(g.tiles_per_img); a.tx_log = ilog2(g.tiles_x);
+  a.g_log = is_pow2(c.cout) ? ilog2(c.cout / DM_GROUPS) : 3;  // (only read when statistics are requested: Cout in {64..512})
+  a.g1_log = ilog2(c.c1 / DM_GROUPS);
   {
     const int ppp = c.kind == 6 ? 64 : (c.bf16 || c.kind == 1) ? 32 : 16;  // 256 threads / (16-byte loads per pixel per chunk)
     a.ppp_q = ppp / g.htw; a.ppp_r = ppp % g.htw;

@@ -82,6 +82,10 @@ struct ConvArgs {
   int pout;               // output partials per image
   int h_log, w_log, c1_log, c2_log, cout_log;  // log2 of H, W, C1, C2, Cout (all powers of two)
   int ppp_q, ppp_r;       // (pixels staged per workgroup load) = ppp_q * htw + ppp_r
+  // Everything the kernels divide by is a power of two; the logs are passed because an integer division
+  // by a run-time value costs ~30 VALU instructions (there is no hardware divide), paid in MFMA time.
+  int tpi_log, tx_log;    // log2 of tiles_per_img, tiles_x
+  int g_log, g1_log;      // log2 of channels per GroupNorm group of the output (Cout/8) and of input 1 (C1/8)
   int ntiles;             // tiles along grid.x (persistent kernels loop: t = blockIdx.x; t < ntiles; t += gridDim.x)
   // init_conv folded into this conv's staging (KIND 0, down1.conv1): when init_x != null the input
   // tile is COMPUTED from the NCHW image (3x3 conv, init_cin -> C1 channels) instead of loaded
@@ -238,13 +242,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
     // cross-lane shuffles and a few LDS words in a fixed order: the result depends neither on
     // the batch size nor on dispatch order.  A 16-row segment never straddles two images.
     constexpr int NSW = MB * 2;                          // 16-row segments per wave
-    const int G = p.Cout / DM_GROUPS;                    // channels per group: 8, 16, 32 or 64
-    const int GL = G < 32 ? G : 32;                      // lanes of one group inside a wave
-    const int gpt = 64 / G;                              // groups in this 64-channel tile
-    const int rows_img = (p.ni > 1) ? (th * tw) : MT;    // tile rows that belong to one image
+    const int G = 1 << p.g_log;                          // channels per group: 8, 16, 32 or 64
+    const int gl_log = p.g_log < 5 ? p.g_log : 5;
+    const int GL = 1 << gl_log;                          // lanes of one group inside a wave
+    const int gpt_log = 6 - p.g_log;
+    const int gpt = 1 << gpt_log;                        // groups in this 64-channel tile
+    const int rows_log = (p.ni > 1) ? (p.th_log + p.tw_log) : (MB == 2 ? 7 : 6);
+    const int rows_img = 1 << rows_log;                  // tile rows that belong to one image
     const bool perseg = rows_img < 32 * MB;              // (then rows_img == 16: one image per segment)
-    const int nimg_t = MT / rows_img;
-    const int gg = (lane & 31) / GL;
+    const int nimg_t = MT >> rows_log;
+    const int gg = (lane & 31) >> gl_log;
     float val[NSW];
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -253,8 +260,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         for (int sg = 0; sg < 2; ++sg) {
           float mu = 0.f;
           if (pass == 1) {
-            const int i = perseg ? (wm * MB + mb) * 2 + sg : (wm * 32 * MB) / rows_img;
-            mu = s_mu[i * gpt + lc / G];
+            const int i = perseg ? (wm * MB + mb) * 2 + sg : (wm * 32 * MB) >> rows_log;
+            mu = s_mu[i * gpt + (lc >> p.g_log)];
           }
           float sm = 0.f;
 #pragma unroll
@@ -276,18 +283,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
           float v = val[k];
           v += __shfl_xor(v, 32, 64);
           for (int o = 1; o < GL; o <<= 1) v += __shfl_xor(v, o, 64);
-          if (h == 0 && ((lane & 31) % GL) == 0) sred[(wave * NSW + k) * 4 + gg] = v;
+          if (h == 0 && ((lane & 31) & (GL - 1)) == 0) sred[(wave * NSW + k) * 4 + gg] = v;
         }
       }
       __syncthreads();
       if (tid < nimg_t * gpt) {
-        const int i = tid / gpt, g = tid - i * gpt;
+        const int i = tid >> gpt_log, g = tid - i * gpt;
         float sm = 0.f;
         // waves (wm) and slots (k) that cover image i; wn / gg that cover group g
-        const int wm0 = perseg ? i / NSW : (i * rows_img) / (32 * MB);
+        const int wm0 = perseg ? i / NSW : (i << rows_log) / (32 * MB);
         const int nwm = perseg ? 1 : (rows_img / (32 * MB));
         const int k = perseg ? i % NSW : 0;
-        const int wn0 = (g * G) >> 5, nwn = (G == 64) ? 2 : 1, g2 = ((g * G) & 31) / GL;
+        const int wn0 = (g * G) >> 5, nwn = (G == 64) ? 2 : 1, g2 = ((g * G) & 31) >> gl_log;
         for (int a = 0; a < nwm; ++a)
           for (int b = 0; b < nwn; ++b) sm += sred[(((wm0 + a) * 2 + wn0 + b) * NSW + k) * 4 + g2];
         if (pass == 0) {
@@ -349,7 +356,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 // GroupNorm tables of one tile: scale = rstd*gamma, shift = beta - mean*scale, temb, per (image, channel),
 // from the producer's (mean, M2) partials merged in a fixed order (Chan et al.).
 __device__ __forceinline__ void gn_tables(const ConvArgs& p, int img0, int tq, float* s_scale, float* s_shift, float* s_temb) {
-  const int G = p.C1 / DM_GROUPS;
   const int step = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
   const float* te = p.temb ? p.temb + (size_t)step * p.temb_step_stride : nullptr;
   for (int idx = tq; idx < p.ni * p.C1; idx += 256) {
@@ -357,7 +363,7 @@ __device__ __forceinline__ void gn_tables(const ConvArgs& p, int img0, int tq, f
     const int n = img0 + i;
     float scale = 0.f, shift = 0.f, tv = 0.f;
     if (n < p.B) {
-      const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c / G)) * 2;
+      const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c >> p.g1_log)) * 2;
       float msum = 0.f;
       for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
       const float mean = msum / (float)p.pin;
@@ -426,10 +432,11 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& p, f32x16 (&acc)[8
     v[k].w = fmaf(sg, t2.w, fmaf(sg, t1.w, t0.w)) + bv.w;
   }
   if (p.stats_out) {
-    const int G = p.Cout / DM_GROUPS;       // channels per group: 8, 16, 32 or 64
+    const int G = 1 << p.g_log;             // channels per group: 8, 16, 32 or 64
     const int qg = G >> 2;                  // channel quads per group
-    const int gpt = 64 / G;                 // groups in this workgroup's 64 channels
-    const int gq = c4 / qg;
+    const int gpt_log = 6 - p.g_log;
+    const int gpt = 1 << gpt_log;           // groups in this workgroup's 64 channels
+    const int gq = c4 >> (p.g_log - 2);
     const int kk_log = tsh - 4;             // log2(k slots per image): rows of one image / 16
     const float inv_cnt = 1.0f / (float)((1 << tsh) * G);
     for (int pass = 0; pass < 2; ++pass) {
@@ -449,7 +456,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& p, f32x16 (&acc)[8
       }
       __syncthreads();
       if (tq < p.ni * gpt) {
-        const int i = tq / gpt, g = tq - i * gpt;
+        const int i = tq >> gpt_log, g = tq - i * gpt;
         const float sm = ((sred[(0 * 8 + i) * 8 + g] + sred[(1 * 8 + i) * 8 + g]) + sred[(2 * 8 + i) * 8 + g]) + sred[(3 * 8 + i) * 8 + g];
         if (pass == 0) {
           s_mu[i * 8 + g] = sm * inv_cnt;
@@ -585,10 +592,10 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
   asm volatile("" : "+v"(tq));
   if (KIND == 4) { par = 0; py = 0; px = 0; }  // (advanced by the previous tile's K loop)
   DM_STAMP_RAW(7);  // (diagnostic build) start of this tile: slots 7,1,2,3 bracket the LAST tile's phases
-  const int img0 = (t / p.tiles_per_img) * p.ni;
-  const int tin = t % p.tiles_per_img;
-  const int y0 = (tin / p.tiles_x) << p.th_log;
-  const int x0 = (tin % p.tiles_x) << p.tw_log;
+  const int img0 = (t >> p.tpi_log) * p.ni;
+  const int tin = t & (p.tiles_per_img - 1);
+  const int y0 = (tin >> p.tx_log) << p.th_log;
+  const int x0 = (tin & (p.tiles_x - 1)) << p.tw_log;
   const int hy0 = (KIND == 0 || KIND == 4 || KIND == 5) ? y0 - 1 : (KIND == 1) ? 2 * y0 - 1 : (KIND == 2) ? y0 - 1 + py : y0;
   const int hx0 = (KIND == 0 || KIND == 4 || KIND == 5) ? x0 - 1 : (KIND == 1) ? 2 * x0 - 1 : (KIND == 2) ? x0 - 1 + px : x0;
 
