@@ -68,7 +68,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("DM_BENCH_FORCE_DIST"))  # rehearsal: a 1-rank RCCL communicator + all-gather
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    saved_stdout = None
+    if world > 1 or force_dist:
+        # RCCL prints a version banner on stdout when its communicator is created (NCCL_DEBUG=VERSION on some
+        # boxes): keep stdout for the ONE JSON line by pointing fd 1 at stderr until that line is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -109,6 +119,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if force_dist and world == 1:  # the collective sample_sharded issues for N > 1, on a 1-rank communicator
+        o1 = one_pass()
+        full = torch.empty_like(o1)
+        dist.all_gather_into_tensor(full, o1)
+        torch.cuda.synchronize()
+        assert torch.equal(full, o1)
+        print("rehearsal: RCCL all_gather_into_tensor ok", file=sys.stderr)
     for _ in range(args.warmup):
         one_pass()
     barrier()
@@ -205,9 +222,13 @@ def main():
             # a throughput number for wrong samples is worthless: refuse to print one
             raise SystemExit(f"bench: GPU samples differ from the CPU oracle by {err:.3g} (> 1e-3) on the first {cb} images")
 
+    if saved_stdout is not None:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
-        print(json.dumps(res))
-    if world > 1:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
         dist.destroy_process_group()
 
 
