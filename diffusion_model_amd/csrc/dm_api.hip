@@ -119,11 +119,11 @@ struct ConvCall {
   const float* init_x; const float* init_w; const float* init_b; int init_cin;  // folded init_conv
 };
 
-template <int MB, int KIND, int KC>
+template <int MB, int KIND, int KC, int GEO = 0>
 int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_done = false;  // benign race: setting the attribute twice is harmless
   if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, KIND, KC>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, KIND, KC, GEO>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -136,7 +136,7 @@ int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   const double taps = (KIND == 0 || KIND == 5) ? 9 : KIND == 1 ? 16 : KIND == 3 ? 1 : 4;
   const int cin = a.C1 + a.C2;
   ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 4.0 * (ipix * cin + opix * a.Cout + taps * (UP ? 4 : 1) * cin * a.Cout));
-  hipLaunchKernelGGL((conv_mfma_kernel<MB, KIND, KC>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<MB, KIND, KC, GEO>), grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -238,8 +238,13 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
     if (c.kind == 2) return g.MT == 128 ? launch_conv_bf16_t<2, 2>(a, grid, lds, s) : launch_conv_bf16_t<1, 2>(a, grid, lds, s);
     return launch_conv_bf16_t<1, 1>(a, grid, lds, s);
   }
-  if (c.kind == 5) return launch_conv_t<2, 5, 64>(a, grid, lds, s);
-  if (c.kind == 6) return launch_conv_t<2, 1, 16>(a, grid, lds, s);
+  if (c.kind == 5) {
+    const bool geo1 = g.th_log == 3 && g.tw_log == 4 && g.ni == 1 && c.c1 == 64 && (c.c2 == 0 || c.c2 == 64) && c.cout == 64;  // GEO=1
+    return geo1 ? launch_conv_t<2, 5, 64, 1>(a, grid, lds, s) : launch_conv_t<2, 5, 64>(a, grid, lds, s);
+  }
+  const bool c64 = c.c1 == 64 && (c.c2 == 0 || c.c2 == 64) && c.cout == 64 && g.ni == 1;  // compile-time geometry (GEO=1)
+  if (c.kind == 6) return (c64 && g.th_log == 4 && g.tw_log == 3) ? launch_conv_t<2, 1, 16, 1>(a, grid, lds, s) : launch_conv_t<2, 1, 16>(a, grid, lds, s);
+  if (fused_up && g.MT == 128 && c64 && c.c2 == 0 && g.th_log == 3 && g.tw_log == 4) return launch_conv_t<2, 4, 64, 1>(a, grid, lds, s);
   if (fused_up) return g.MT == 128 ? launch_conv_t<2, 4, 64>(a, grid, lds, s) : launch_conv_t<1, 4, 64>(a, grid, lds, s);
   (void)cin;
   if (c.kind == 0) return g.MT == 128 ? launch_conv_t<2, 0, 64>(a, grid, lds, s) : launch_conv_t<1, 0, 64>(a, grid, lds, s);

@@ -481,8 +481,22 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& p, f32x16 (&acc)[8
   }
 }
 
-template <int MB, int KIND, int KC>
-__global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const ConvArgs p) {
+// GEO = 1 (KIND 5 only): the geometry of the model's large 3x3 layers is a compile-time fact — tile 8x16 pixels of
+// one image, 64 input channels per pointer, 64 output channels — so the index math folds to constants.
+template <int MB, int KIND, int KC, int GEO = 0>
+__global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const ConvArgs p_in) {
+  ConvArgs p = p_in;
+  if constexpr (GEO == 1) {
+    // 128-pixel tiles of one image: 8x16 (3x3 and transposed convs: halo 10x18, the fused transposed conv
+    // included) or 16x8 outputs of the stride-2 conv (halo 34x18); 64 channels per input pointer, 64 outputs
+    static_assert(MB == 2 && (KIND == 5 || KIND == 4 || KIND == 1), "GEO=1 instantiations");
+    constexpr int HTH = (KIND == 1) ? 34 : 10, HTW = 18;
+    p.th_log = (KIND == 1) ? 4 : 3; p.tw_log = (KIND == 1) ? 3 : 4; p.ni = 1; p.hth = HTH; p.htw = HTW;
+    p.mg_htw = (unsigned)((0x100000000ull + HTW - 1) / HTW); p.mg_hth = (unsigned)((0x100000000ull + HTH - 1) / HTH);
+    constexpr int PPPX = (KIND == 5) ? 16 : 256 / (KC / 4);
+    p.ppp_q = PPPX / HTW; p.ppp_r = PPPX % HTW;
+    p.C1 = 64; p.c1_log = 6; p.c2_log = 6; p.Cout = 64; p.cout_log = 6; p.g_log = 3; p.g1_log = 3;
+  }
   constexpr int MT = 64 * MB;
   constexpr bool WINO = (KIND == 5);
   constexpr int RS = KC + 4;  // LDS row stride (floats): 16-B skew between consecutive pixels
