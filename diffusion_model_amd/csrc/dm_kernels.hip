@@ -657,6 +657,9 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
         v[u] = *reinterpret_cast<const float4*>(srcb + off);
         inbm |= inb ? (1u << u) : 0u;
       }
+      // (opaque: otherwise hipcc keeps the 26 halo coordinates alive - spilled - and redoes the four
+      // comparisons per element below instead of testing one bit)
+      asm volatile("" : "+v"(inbm));
       if (tf && chunk == 0) {
         gn_tables(p, img0, tq, s_scale, s_shift, s_temb);  // while the tile loads are in flight
         __syncthreads();
