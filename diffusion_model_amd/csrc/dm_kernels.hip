@@ -648,12 +648,13 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
 #pragma unroll
       for (int u = 0; u < UW; ++u) {
         const int k = pk[u];
-        const int hxu = (k >> 16) & 63, hyu = (k >> 22) & 63, iu = (k >> 28) & 7;
+        const int hxu = (k >> 16) & 63, hyu = (k >> 22) & 63;
+        const int iu = (p.ni == 1) ? 0 : (k >> 28) & 7;  // (one image per tile: the grid covers exactly B images)
         const int iy = hy0 + hyu, ix = hx0 + hxu;
-        const bool inb = k >= 0 && iu <= imax && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const bool inb = k >= 0 && (p.ni == 1 || iu <= imax) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         // unconditional load from a clamped (always valid) address; padding is a select afterwards
         const int lin = min(max((iy << p.w_log) + ix, 0), hw1);
-        const unsigned off = (unsigned)((min(iu, imax) << (p.h_log + p.w_log)) + lin) << cs_log;
+        const unsigned off = (unsigned)((((p.ni == 1) ? 0 : min(iu, imax)) << (p.h_log + p.w_log)) + lin) << cs_log;
         v[u] = *reinterpret_cast<const float4*>(srcb + off);
         inbm |= inb ? (1u << u) : 0u;
       }
