@@ -28,6 +28,22 @@ __device__ __forceinline__ float dm_silu_add(float v, float t) {
   return fmaf(v, __builtin_amdgcn_rcpf(1.0f + e), t);
 }
 
+// four of them with the multiply and the add packed (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32); same
+// operations and roundings as dm_silu_add
+typedef float dm_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 dm_silu_add4(float4 g, float4 t) {
+  const dm_f32x2 nl2e = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.f, 1.f};
+  const dm_f32x2 a = {g.x, g.y}, b = {g.z, g.w};
+  const dm_f32x2 ea = a * nl2e, eb = b * nl2e;
+  const dm_f32x2 da = dm_f32x2{__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)} + one;
+  const dm_f32x2 db = dm_f32x2{__builtin_amdgcn_exp2f(eb.x), __builtin_amdgcn_exp2f(eb.y)} + one;
+  const dm_f32x2 ra = {__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y)};
+  const dm_f32x2 rb = {__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y)};
+  const dm_f32x2 oa = __builtin_elementwise_fma(a, ra, dm_f32x2{t.x, t.y});
+  const dm_f32x2 ob = __builtin_elementwise_fma(b, rb, dm_f32x2{t.z, t.w});
+  return make_float4(oa.x, oa.y, ob.x, ob.y);
+}
+
 // ------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on fp32 MFMA.
 //   KIND 0: Conv2d 3x3 s1 p1      KIND 1: Conv2d 4x4 s2 p1      KIND 2: ConvTranspose2d 4x4 s2 p1
@@ -680,8 +696,7 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
             w.x = fmaf(w.x, sc.x, sh.x); w.y = fmaf(w.y, sc.y, sh.y);
             w.z = fmaf(w.z, sc.z, sh.z); w.w = fmaf(w.w, sc.w, sh.w);
             if (p.tf_silu) {
-              w.x = dm_silu_add(w.x, te.x); w.y = dm_silu_add(w.y, te.y);
-              w.z = dm_silu_add(w.z, te.z); w.w = dm_silu_add(w.w, te.w);
+              w = dm_silu_add4(w, te);
             } else {
               w.x += te.x; w.y += te.y; w.z += te.z; w.w += te.w;
             }
