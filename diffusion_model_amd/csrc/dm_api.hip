@@ -217,6 +217,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
     if (lds_f < DM_WINO_EPI_FLOATS) lds_f = DM_WINO_EPI_FLOATS;
     lds_f += 208;  // staging descriptor table
     if (np > 208) return fail("conv: Winograd tile has %zu halo pixels (> 208)", np);
+    if ((np + 1) * 68 + (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + 208 > lds_f) return fail("conv: no room for the staging dump row");
   }
   if (c.bf16) {
     lds_f = (np * (64 + 8) + 1) / 2 + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0) + init_f;

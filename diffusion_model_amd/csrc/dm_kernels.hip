@@ -607,7 +607,9 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
       const int ii = __umulhi((unsigned)r, p.mg_hth);
       const int hy = r - ii * hth;
       const int lofs = (((ii * 4 + (hy & 1) * 2 + (hx & 1)) * PH + (hy >> 1)) * PW + (hx >> 1)) * RS;
-      ptab[tid] = (pix < NP) ? (lofs | (hx << 16) | (hy << 22) | (ii << 28)) : (int)0x80000000;
+      // entries past the tile point at a dump row behind it: they are written like the rest (as zeros), so the
+      // staging loop has no divergent branch and the scheduler can interleave the elements' dependency chains
+      ptab[tid] = (pix < NP) ? (lofs | (hx << 16) | (hy << 22) | (ii << 28)) : (int)(0x80000000u | (unsigned)(NP * RS));
     }
     __syncthreads();
   }
@@ -681,28 +683,40 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
         gn_tables(p, img0, tq, s_scale, s_shift, s_temb);  // while the tile loads are in flight
         __syncthreads();
       }
+      // three straight-line variants (the uniform conditions are hoisted out of the element loop)
+      auto put = [&](int u, float4 w) {
+        if (!((inbm >> u) & 1)) w = make_float4(0.f, 0.f, 0.f, 0.f);  // padding (and the dump row) stays exactly 0
+        *reinterpret_cast<float4*>(tile + (pk[u] & 0xffff)) = w;
+      };
+      auto gn = [&](int u, float4& te) {
+        // table entries come from LDS every time (three 16-byte reads, no VALU): holding them in
+        // 12 registers across the loop spills beside the 128 accumulators
+        const int tofs = ((p.ni == 1) ? 0 : (((pk[u] >> 28) & 7) << p.c1_log)) + coff + c4 * 4;
+        const float4 sc = *reinterpret_cast<const float4*>(s_scale + tofs);
+        const float4 sh = *reinterpret_cast<const float4*>(s_shift + tofs);
+        te = *reinterpret_cast<const float4*>(s_temb + tofs);
+        float4 w = v[u];
+        w.x = fmaf(w.x, sc.x, sh.x); w.y = fmaf(w.y, sc.y, sh.y);
+        w.z = fmaf(w.z, sc.z, sh.z); w.w = fmaf(w.w, sc.w, sh.w);
+        return w;
+      };
+      if (!tf) {
 #pragma unroll
-      for (int u = 0; u < UW; ++u) {
-        const int k = pk[u];
-        if (k >= 0) {
-          float4 w = v[u];
-          if (tf) {
-            // table entries come from LDS every time (three 16-byte reads, no VALU): holding them in
-            // 12 registers across the loop spills beside the 128 accumulators
-            const int tofs = (((k >> 28) & 7) << p.c1_log) + coff + c4 * 4;
-            const float4 sc = *reinterpret_cast<const float4*>(s_scale + tofs);
-            const float4 sh = *reinterpret_cast<const float4*>(s_shift + tofs);
-            const float4 te = *reinterpret_cast<const float4*>(s_temb + tofs);
-            w.x = fmaf(w.x, sc.x, sh.x); w.y = fmaf(w.y, sc.y, sh.y);
-            w.z = fmaf(w.z, sc.z, sh.z); w.w = fmaf(w.w, sc.w, sh.w);
-            if (p.tf_silu) {
-              w = dm_silu_add4(w, te);
-            } else {
-              w.x += te.x; w.y += te.y; w.z += te.z; w.w += te.w;
-            }
-          }
-          if (!((inbm >> u) & 1)) w = make_float4(0.f, 0.f, 0.f, 0.f);  // padding stays exactly 0
-          *reinterpret_cast<float4*>(tile + (k & 0xffff)) = w;
+        for (int u = 0; u < UW; ++u) put(u, v[u]);
+      } else if (p.tf_silu) {
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+          float4 te;
+          const float4 w = gn(u, te);
+          put(u, dm_silu_add4(w, te));
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+          float4 te;
+          float4 w = gn(u, te);
+          w.x += te.x; w.y += te.y; w.z += te.z; w.w += te.w;
+          put(u, w);
         }
       }
     } else
