@@ -502,6 +502,13 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& p, f32x16 (&acc)[8
 template <int MB, int KIND, int KC, int GEO = 0>
 __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const ConvArgs p_in) {
   ConvArgs p = p_in;
+  if constexpr (GEO == 2) {  // KIND 5 on 8x8 images: two whole images per tile (halo 10x10 each), 64 -> 64 channels
+    static_assert(MB == 2 && KIND == 5, "GEO=2 instantiation");
+    p.th_log = 3; p.tw_log = 3; p.ni = 2; p.hth = 10; p.htw = 10;
+    p.mg_htw = (unsigned)((0x100000000ull + 9) / 10); p.mg_hth = p.mg_htw;
+    p.H = 8; p.W = 8; p.h_log = 3; p.w_log = 3; p.tiles_per_img = 1; p.tiles_x = 1; p.tpi_log = 0; p.tx_log = 0;
+    p.C1 = 64; p.c1_log = 6; p.c2_log = 6; p.Cout = 64; p.cout_log = 6; p.g_log = 3; p.g1_log = 3;
+  }
   if constexpr (GEO == 1) {
     // 128-pixel tiles of one image: 8x16 (3x3 and transposed convs: halo 10x18, the fused transposed conv
     // included) or 16x8 outputs of the stride-2 conv (halo 34x18); 64 channels per input pointer, 64 outputs
