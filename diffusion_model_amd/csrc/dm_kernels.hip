@@ -245,7 +245,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         const int x = x0 + (m & (tw - 1));
         const int y = y0 + ((m >> p.tw_log) & (th - 1));
         const int n = img0 + (m >> (p.tw_log + p.th_log));
-        if (n < p.B) {
+        if (p.ni == 1 || n < p.B) {  // (one image per tile: the grid covers exactly B images)
           const int oy = UP ? 2 * y + py : y, ox = UP ? 2 * x + px : x;
           p.y[(((size_t)n * OH + oy) * OW + ox) * p.Cout + blockIdx.y * 64 + lc] = acc[mb][r];
         }
@@ -317,7 +317,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
           s_mu[tid] = sm / (float)(rows_img * G);
         } else {
           const int n = img0 + i;
-          if (n < p.B) {
+          if (p.ni == 1 || n < p.B) {  // (one image per tile: the grid covers exactly B images)
             const int pidx = (UP ? par * p.tiles_per_img : 0) + tin;
             float* so = p.stats_out + (((size_t)n * p.pout + pidx) * DM_GROUPS + blockIdx.y * gpt + g) * 2;
             so[0] = s_mu[tid];
@@ -339,7 +339,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
       const int x = x0 + (m & (tw - 1));
       const int y = y0 + ((m >> p.tw_log) & (th - 1));
       const int n = img0 + (m >> (p.tw_log + p.th_log));
-      if (n < p.B) {
+      if (p.ni == 1 || n < p.B) {  // (one image per tile: the grid covers exactly B images)
         const int oy = UP ? 2 * y + py : y;
         const int ox = UP ? 2 * x + px : x;
         const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(otile) + m * 72 + c8 * 8);
@@ -355,7 +355,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
     const int x = x0 + (m & (tw - 1));
     const int y = y0 + ((m >> p.tw_log) & (th - 1));
     const int n = img0 + (m >> (p.tw_log + p.th_log));
-    if (n < p.B) {
+    if (p.ni == 1 || n < p.B) {  // (one image per tile: the grid covers exactly B images)
       const int oy = UP ? 2 * y + py : y;
       const int ox = UP ? 2 * x + px : x;
       float4 v = *reinterpret_cast<const float4*>(otile + m * ORS + c4 * 4);
@@ -378,7 +378,7 @@ __device__ __forceinline__ void gn_tables(const ConvArgs& p, int img0, int tq, f
     const int i = idx >> p.c1_log, c = idx & (p.C1 - 1);
     const int n = img0 + i;
     float scale = 0.f, shift = 0.f, tv = 0.f;
-    if (n < p.B) {
+    if (p.ni == 1 || n < p.B) {  // (one image per tile: the grid covers exactly B images)
       const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c >> p.g1_log)) * 2;
       float msum = 0.f;
       for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
@@ -478,7 +478,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& p, f32x16 (&acc)[8
           s_mu[i * 8 + g] = sm * inv_cnt;
         } else {
           const int n = img0 + i;
-          if (n < p.B) {
+          if (p.ni == 1 || n < p.B) {  // (one image per tile: the grid covers exactly B images)
             float* so = p.stats_out + (((size_t)n * p.pout + tin) * DM_GROUPS + blockIdx.y * gpt + g) * 2;
             so[0] = s_mu[i * 8 + g];
             so[1] = sm;
@@ -492,7 +492,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& p, f32x16 (&acc)[8
   for (int k = 0; k < 8; ++k) {
     const int m = p0 + 16 * k;
     const int x = x0 + (m & (tw - 1)), y = y0 + ((m >> p.tw_log) & (th - 1)), n = img0 + (m >> tsh);
-    if (n < p.B)
+    if (p.ni == 1 || n < p.B)
       *reinterpret_cast<float4*>(p.y + ((((size_t)n * p.H + y) * p.W + x) * p.Cout + blockIdx.y * 64 + c4 * 4)) = v[k];
   }
 }
