@@ -233,6 +233,9 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
     const unsigned slots = c.kind == 5 ? 512u : 768u;
     const unsigned resident = slots / (grid.y * grid.z) ? slots / (grid.y * grid.z) : 1u;
     if (grid.x > resident) grid.x = resident;
+    a.ngroups = groups;
+    // XCD-aware tile order once every XCD has several rounds of work (exact only for 8 | grid.x)
+    a.xcd_map = (grid.x % 8 == 0 && grid.y == 1 && grid.z == 1 && groups >= 64) ? 1 : 0;
   }
   if (c.bf16) {
     if (c.kind == 0) return g.MT == 128 ? launch_conv_bf16_t<2, 0>(a, grid, lds, s) : launch_conv_bf16_t<1, 0>(a, grid, lds, s);

@@ -102,6 +102,8 @@ struct ConvArgs {
   // by a run-time value costs ~30 VALU instructions (there is no hardware divide), paid in MFMA time.
   int tpi_log, tx_log;    // log2 of tiles_per_img, tiles_x
   int g_log, g1_log;      // log2 of channels per GroupNorm group of the output (Cout/8) and of input 1 (C1/8)
+  int ngroups;            // image groups (ceil(B / ni)); xcd_map: tiles are dealt to workgroups per XCD (see the tile loop)
+  int xcd_map;
   int ntiles;             // tiles along grid.x (persistent kernels loop: t = blockIdx.x; t < ntiles; t += gridDim.x)
   // init_conv folded into this conv's staging (KIND 0, down1.conv1): when init_x != null the input
   // tile is COMPUTED from the NCHW image (3x3 conv, init_cin -> C1 channels) instead of loaded
@@ -624,7 +626,16 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
   // Persistent workgroups: the grid is at most 3 per CU and each workgroup walks tiles
   // t, t + gridDim.x, ...  (a finished workgroup's slot otherwise stays empty for 2-16 k cycles
   // until the dispatcher refills it: ~4 % of a CU's time at 160 k cycles per tile)
-  for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+  // XCD-aware order (xcd_map; needs gridDim.x % 8 == 0): hardware deals workgroups to the 8 XCDs round-robin, so
+  // workgroup b runs on XCD b & 7.  Image group g is given to XCD g & 7 and that XCD's workgroups (b >> 3) walk ITS
+  // tiles in order: the tiles of one image - which share halo rows - are staged by neighbouring workgroups of one
+  // XCD at about the same time and meet in that XCD's L2 instead of being fetched once per XCD.
+  const int t_first = p.xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t_step = p.xcd_map ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int t_xcd = p.xcd_map ? (int)(blockIdx.x & 7) : 0;
+  const int t_end = p.xcd_map ? (((p.ngroups - t_xcd + 7) >> 3) << p.tpi_log) : p.ntiles;
+  for (int ts = t_first; ts < t_end; ts += t_step) {
+  const int t = p.xcd_map ? (((((ts >> p.tpi_log) << 3) + t_xcd) << p.tpi_log) | (ts & (p.tiles_per_img - 1))) : ts;
   // opaque copy of the thread id: index math derived from it is recomputed per tile instead of
   // being hoisted out of this loop and held in (spilled) registers across the K loop
   int tq = threadIdx.x;
