@@ -168,8 +168,18 @@ __device__ __forceinline__ void stage_init_tile(const ConvArgs& p, void* tile_v,
   if (tid < 64) bl[tid] = p.init_b[chan0 + tid];
   __syncthreads();
   const int NP = p.ni * hth * htw;
+  // idx = tid + 256 k: the channel quad (idx & 15) never changes for a thread, so with one input channel its nine
+  // weight quads and the bias are read from LDS once per tile, not once per pixel
+  const int c4 = tid & 15;
+  float4 wreg[9];
+  const bool wr = !BF && Ci == 1;  // (the bf16 kernel runs 4 waves/SIMD on 128 registers: no room for 36 more)
+  if (wr) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wreg[k] = *reinterpret_cast<const float4*>(wl + k * 64 + c4 * 4);
+  }
+  const float4 breg = *reinterpret_cast<const float4*>(bl + c4 * 4);
   for (int idx = tid; idx < NP * 16; idx += 256) {
-    const int pix = idx >> 4, c4 = idx & 15;
+    const int pix = idx >> 4;
     const int r = __umulhi((unsigned)pix, p.mg_htw);
     const int hx = pix - r * htw;
     const int i = __umulhi((unsigned)r, p.mg_hth);
@@ -177,17 +187,29 @@ __device__ __forceinline__ void stage_init_tile(const ConvArgs& p, void* tile_v,
     const int iy = hy0 + hy, ix = hx0 + hx, n = img0 + i;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-      a = *reinterpret_cast<const float4*>(bl + c4 * 4);
-      for (int ci = 0; ci < Ci; ++ci) {
-        const float* xp = xs + ((i * Ci + ci) * ph + hy) * pw + hx;
+      a = breg;
+      if (wr) {  // same summation order as the general form below
+        const float* xp = xs + (i * ph + hy) * pw + hx;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             const float xv = xp[ky * pw + kx];
-            const float4 wv = *reinterpret_cast<const float4*>(wl + (ci * 9 + ky * 3 + kx) * 64 + c4 * 4);
+            const float4 wv = wreg[ky * 3 + kx];
             a.x += xv * wv.x; a.y += xv * wv.y; a.z += xv * wv.z; a.w += xv * wv.w;
           }
+      } else {
+        for (int ci = 0; ci < Ci; ++ci) {
+          const float* xp = xs + ((i * Ci + ci) * ph + hy) * pw + hx;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const float xv = xp[ky * pw + kx];
+              const float4 wv = *reinterpret_cast<const float4*>(wl + (ci * 9 + ky * 3 + kx) * 64 + c4 * 4);
+              a.x += xv * wv.x; a.y += xv * wv.y; a.z += xv * wv.z; a.w += xv * wv.w;
+            }
+        }
       }
     }
     // Winograd kernel: the tile is stored as four (row parity, column parity) planes per image
