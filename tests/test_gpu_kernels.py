@@ -181,6 +181,26 @@ def test_conv_large_batch_rows_match_small_batch(kind):
         assert torch.equal(y[lo:hi], y2) and torch.equal(st[lo:hi], st2), (kind, lo)
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2, 5, 6])
+def test_conv_xcd_tile_order_uneven_groups(kind):
+    """131 images at 32x32: every kernel runs its XCD-aware tile order (image group g on XCD g & 7) with a
+    different number of groups per XCD; all rows must equal what the images give alone, and the reference."""
+    torch.manual_seed(40 + kind)
+    B, H = 131, 32
+    x = torch.randn(B, 64, H, H)
+    k = 3 if kind in (0, 5) else 4
+    w, b = torch.randn(64, 64, k, k) * 0.05, torch.randn(64)
+    y, st = run_conv(kind, x, None, w, b, want_stats=True)
+    assert torch.isfinite(y).all() and torch.isfinite(st).all()
+    for lo, hi in ((0, 9), (60, 70), (120, 131)):
+        y2, st2 = run_conv(kind, x[lo:hi].contiguous(), None, w, b, want_stats=True)
+        assert torch.equal(y[lo:hi], y2) and torch.equal(st[lo:hi], st2), (kind, lo)
+    xs = x[125:131]
+    ref = (F.conv2d(xs, w, b, padding=1) if kind in (0, 5) else F.conv2d(xs, w, b, stride=2, padding=1) if kind in (1, 6)
+           else F.conv_transpose2d(xs, w, b, stride=2, padding=1))
+    assert (y[125:131] - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("H", [16, 4])
 def test_conv_concat(H):
     torch.manual_seed(5)
