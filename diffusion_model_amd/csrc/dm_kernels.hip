@@ -404,14 +404,28 @@ __device__ __forceinline__ void gn_tables(const ConvArgs& p, int img0, int tq, f
     float scale = 0.f, shift = 0.f, tv = 0.f;
     if (p.ni == 1 || n < p.B) {  // (one image per tile: the grid covers exactly B images)
       const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c >> p.g1_log)) * 2;
-      float msum = 0.f;
-      for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
-      const float mean = msum / (float)p.pin;
-      float m2 = 0.f, dev = 0.f;
-      for (int q = 0; q < p.pin; ++q) {
-        const float d = st[q * DM_GROUPS * 2] - mean;
-        m2 += st[q * DM_GROUPS * 2 + 1];
-        dev += d * d;
+      float msum = 0.f, mean, m2 = 0.f, dev = 0.f;
+      if (p.pin <= 8) {  // the usual case: all partials in ONE round of independent 8-byte loads, same arithmetic
+        float2 pr[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pr[q] = *reinterpret_cast<const float2*>(st + (q < p.pin ? q : 0) * DM_GROUPS * 2);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q < p.pin) msum += pr[q].x;
+        mean = msum / (float)p.pin;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q < p.pin) {
+          const float d = pr[q].x - mean;
+          m2 += pr[q].y;
+          dev += d * d;
+        }
+      } else {
+        for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
+        mean = msum / (float)p.pin;
+        for (int q = 0; q < p.pin; ++q) {
+          const float d = st[q * DM_GROUPS * 2] - mean;
+          m2 += st[q * DM_GROUPS * 2 + 1];
+          dev += d * d;
+        }
       }
       const float var = (m2 + p.cnt_in * dev) / (p.cnt_in * (float)p.pin);
       scale = rsqrtf(var + DM_GN_EPS) * p.gamma[c];
