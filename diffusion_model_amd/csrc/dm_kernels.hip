@@ -1130,14 +1130,28 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
   const int G = C / DM_GROUPS;
   for (int c = threadIdx.x; c < C; c += 256) {
     const float* st = stats + ((size_t)n * pin * DM_GROUPS + c / G) * 2;
-    float msum = 0.f;
-    for (int q = 0; q < pin; ++q) msum += st[q * DM_GROUPS * 2];
-    const float mean = msum / (float)pin;
-    float m2 = 0.f, dev = 0.f;
-    for (int q = 0; q < pin; ++q) {
-      const float d = st[q * DM_GROUPS * 2] - mean;
-      m2 += st[q * DM_GROUPS * 2 + 1];
-      dev += d * d;
+    float msum = 0.f, mean, m2 = 0.f, dev = 0.f;
+    if (pin <= 8) {  // all partials in one round of independent loads (same arithmetic)
+      float2 pr[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pr[q] = *reinterpret_cast<const float2*>(st + (q < pin ? q : 0) * DM_GROUPS * 2);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (q < pin) msum += pr[q].x;
+      mean = msum / (float)pin;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (q < pin) {
+        const float d = pr[q].x - mean;
+        m2 += pr[q].y;
+        dev += d * d;
+      }
+    } else {
+      for (int q = 0; q < pin; ++q) msum += st[q * DM_GROUPS * 2];
+      mean = msum / (float)pin;
+      for (int q = 0; q < pin; ++q) {
+        const float d = st[q * DM_GROUPS * 2] - mean;
+        m2 += st[q * DM_GROUPS * 2 + 1];
+        dev += d * d;
+      }
     }
     const float var = (m2 + cnt_in * dev) / (cnt_in * (float)pin);
     s_mean[c] = mean;
