@@ -110,14 +110,28 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const ConvArgs p) {
           float mean = 0.f, scale = 0.f, tv = 0.f;
           if (n < p.B) {
             const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c / G)) * 2;
-            float msum = 0.f;
-            for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
-            mean = msum / (float)p.pin;
-            float m2 = 0.f, dev = 0.f;
-            for (int q = 0; q < p.pin; ++q) {
-              const float d = st[q * DM_GROUPS * 2] - mean;
-              m2 += st[q * DM_GROUPS * 2 + 1];
-              dev += d * d;
+            float msum = 0.f, m2 = 0.f, dev = 0.f;
+            if (p.pin <= 8) {  // all partials in one round of independent loads (same arithmetic)
+              float2 pr[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) pr[q] = *reinterpret_cast<const float2*>(st + (q < p.pin ? q : 0) * DM_GROUPS * 2);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) if (q < p.pin) msum += pr[q].x;
+              mean = msum / (float)p.pin;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) if (q < p.pin) {
+                const float d = pr[q].x - mean;
+                m2 += pr[q].y;
+                dev += d * d;
+              }
+            } else {
+              for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
+              mean = msum / (float)p.pin;
+              for (int q = 0; q < p.pin; ++q) {
+                const float d = st[q * DM_GROUPS * 2] - mean;
+                m2 += st[q * DM_GROUPS * 2 + 1];
+                dev += d * d;
+              }
             }
             const float var = (m2 + p.cnt_in * dev) / (p.cnt_in * (float)p.pin);
             scale = rsqrtf(var + DM_GN_EPS) * p.gamma[c];
