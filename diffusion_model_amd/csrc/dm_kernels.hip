@@ -395,8 +395,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 
 // GroupNorm tables of one tile: scale = rstd*gamma, shift = beta - mean*scale, temb, per (image, channel),
 // from the producer's (mean, M2) partials merged in a fixed order (Chan et al.).
-__device__ __forceinline__ void gn_tables(const ConvArgs& p, int img0, int tq, float* s_scale, float* s_shift, float* s_temb) {
-  const int step = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
+__device__ __forceinline__ void gn_tables(const ConvArgs& p, int step, int img0, int tq, float* s_scale, float* s_shift, float* s_temb) {
   const float* te = p.temb ? p.temb + (size_t)step * p.temb_step_stride : nullptr;
   for (int idx = tq; idx < p.ni * p.C1; idx += 256) {
     const int i = idx >> p.c1_log, c = idx & (p.C1 - 1);
@@ -567,6 +566,9 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
   constexpr int NT = NTY * NTY;
   constexpr int NJ = KC / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // the sampling loop's device-side step counter, read ONCE (it selects the time-embedding row): per tile it would
+  // put a second dependent global load in front of the table computation
+  const int step_now = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
 
   DM_STAMP(0);
   // Staging and epilogue ask for raised wave priority, the K loop for 0.  (Measured effect: small.
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
       // comparisons per element below instead of testing one bit)
       asm volatile("" : "+v"(inbm));
       if (tf && chunk == 0) {
-        gn_tables(p, img0, tq, s_scale, s_shift, s_temb);  // while the tile loads are in flight
+        gn_tables(p, step_now, img0, tq, s_scale, s_shift, s_temb);  // while the tile loads are in flight
         __syncthreads();
       }
       // three straight-line variants (the uniform conditions are hoisted out of the element loop)
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
         if (tf && chunk == 0 && base == 0) {
           // GroupNorm tables (scale, shift = beta - mean*scale, temb per (image, channel)),
           // computed while the first batch of tile loads is in flight
-          gn_tables(p, img0, tq, s_scale, s_shift, s_temb);
+          gn_tables(p, step_now, img0, tq, s_scale, s_shift, s_temb);
           __syncthreads();  // uniform condition
         }
         float4 hsc, hsh;  // with one image per tile the thread's table entries never change
