@@ -231,12 +231,14 @@ __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((unsign
 template <int MB, int KIND, bool BF = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[MB], float* scratch, float* otile,
                                               int par, int py, int px, int img0, int tin, int y0, int x0,
-                                              int wm, int wn, int lane, int h, int tid, int wave) {
+                                              int wm, int wn, int lane, int h, int tid, int wave, float bv_pre = 0.f, bool bv_have = false) {
   constexpr int MT = 64 * MB;
   constexpr bool UP = (KIND == 2 || KIND == 4);
   const int th = 1 << p.th_log, tw = 1 << p.tw_log;
   const int lc = wn * 32 + (lane & 31);  // column inside this workgroup's 64 output channels
-  const float bv = p.bias[blockIdx.y * 64 + lc];
+  // (fp32 kernels pass the thread's bias value, loaded once per kernel: a global load here sits in front of the
+  //  first dependent add of every epilogue - four per tile in the fused transposed conv)
+  const float bv = bv_have ? bv_pre : p.bias[blockIdx.y * 64 + lc];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -569,6 +571,8 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
   // the sampling loop's device-side step counter, read ONCE (it selects the time-embedding row): per tile it would
   // put a second dependent global load in front of the table computation
   const int step_now = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
+  // this thread's output-channel bias in the direct kernels' accumulator layout (channel wn*32 + lane&31)
+  const float bias_lane = WINO ? 0.f : p.bias[blockIdx.y * 64 + ((threadIdx.x >> 6) & 1) * 32 + (threadIdx.x & 31)];
 
   DM_STAMP(0);
   // Staging and epilogue ask for raised wave priority, the K loop for 0.  (Measured effect: small.
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
         // one output parity is complete: store it (registers -> HBM; the input tile stays in
         // LDS for the next parity), emit its statistics partial, restart the accumulators
         par = tap >> 2; py = par >> 1; px = par & 1;
-        conv_epilogue<MB, KIND>(p, acc, tile + NP * RS, nullptr, par, py, px, img0, tin, y0, x0, (tq >> 7) & 1, (tq >> 6) & 1, tq & 63, (tq >> 5) & 1, tq, tq >> 6);
+        conv_epilogue<MB, KIND>(p, acc, tile + NP * RS, nullptr, par, py, px, img0, tin, y0, x0, (tq >> 7) & 1, (tq >> 6) & 1, tq & 63, (tq >> 5) & 1, tq, tq >> 6, bias_lane, true);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -1002,7 +1006,7 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
     wino_epilogue(p, acc, smem_b, img0, tin, y0, x0, tq);
   } else if constexpr (KIND != 4) {
     __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
-    conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, (tq >> 7) & 1, (tq >> 6) & 1, tq & 63, (tq >> 5) & 1, tq, tq >> 6);
+    conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, (tq >> 7) & 1, (tq >> 6) & 1, tq & 63, (tq >> 5) & 1, tq, tq >> 6, bias_lane, true);
   }
   __syncthreads();  // LDS (output staging / reduction words) is free again for the next tile
   }  // tile loop
