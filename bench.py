@@ -155,7 +155,7 @@ def main():
         "frac_fp32_mfma_peak_whole_path": value * n * FLOP_PER_IMAGE_STEP / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
     }
 
-    if rank == 0 and world == 1 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline:  # (any N: rank 0's own kernels; the other ranks wait at the final barrier)
         L = _lib.lib()
         ws = model.workspace(B, 32, 32)
         packed = model.packed_weights()
@@ -229,6 +229,8 @@ def main():
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
+        if world > 1:
+            dist.barrier()  # rank 0 may still be in its roofline leg
         dist.destroy_process_group()
 
 
