@@ -68,8 +68,15 @@ class _SamplerBase:
         B, Cin, H, W = x_T.shape
         n = timesteps.numel()
         x = x_T.to(dev, torch.float32).contiguous().clone()
-        ts_dev = timesteps.to(dev, torch.int64).contiguous()
-        coefs = self.scheduler.step_coefs(timesteps, self.eta).to(dev)
+        # device copies of the timestep list and the per-step coefficient table, kept across calls (they depend on
+        # the scheduler tables, the timesteps and eta only): a pageable H2D copy is a host-side sync point per pass
+        src = getattr(self, "_dev_tables_src", None)  # (identity + version of the source tensors: no D2H read-back)
+        if (src is None or src[0] is not timesteps or src[1] != timesteps._version or src[2] != (dev, float(self.eta))
+                or src[3] is not self.scheduler.alphas_cumprod):
+            self._dev_tables = (timesteps.to(dev, torch.int64).contiguous(),
+                                self.scheduler.step_coefs(timesteps, self.eta).to(dev))
+            self._dev_tables_src = (timesteps, timesteps._version, (dev, float(self.eta)), self.scheduler.alphas_cumprod)
+        ts_dev, coefs = self._dev_tables
         nz = None if noises is None else noises.to(dev, torch.float32).contiguous()
         if cond is not None:
             cond = cond.to(dev, torch.float32).contiguous()
