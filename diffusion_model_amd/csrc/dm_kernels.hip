@@ -803,6 +803,11 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
         for (int u = 0; u < U; ++u) {
           if constexpr (GEO == 1) {  // compile-time halo width, one image: direct (hy, hx), no carried state
             hy = pix / htw; hx = pix - hy * htw; ii = 0;
+          } else {  // run-time geometry: two multiply-high divisions, still branch-free and without carried state
+            const int r = __umulhi((unsigned)pix, p.mg_htw);
+            hx = pix - r * htw;
+            ii = __umulhi((unsigned)r, p.mg_hth);
+            hy = r - ii * hth;
           }
           const int iy = hy0 + hy, ix = hx0 + hx;
           const bool valid = pix < NP;
@@ -819,11 +824,7 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
           meta[u] = valid ? (lofs | (inb ? (((ii << p.c1_log) + coff + c4 * 4 + 1) << 16) : 0)) : -1;
           pix += PPP;
           if (!WINO) lofs += PPP * RS;
-          if constexpr (GEO != 1) {
-            hx += p.ppp_r; hy += p.ppp_q;
-            if (hx >= htw) { hx -= htw; ++hy; }
-            while (hy >= hth) { hy -= hth; ++ii; }
-          }
+
         }
         if (tf && chunk == 0 && base == 0) {
           // GroupNorm tables (scale, shift = beta - mean*scale, temb per (image, channel)),
