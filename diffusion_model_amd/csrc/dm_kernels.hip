@@ -1171,6 +1171,46 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
   const int LP = V < 64 ? V : 64;      // lanes per pixel (power of two)
   const int ppp = 256 / LP;            // pixels per pass
   const int q = threadIdx.x % LP;
+  if (C == 64) {
+    // C = 64: 16 lanes per pixel, 4 pixels per thread and slab.  One load per thread in flight keeps only half of
+    // the bytes in the air that 8 TB/s x 2 us needs (Little), so a slab's four loads are issued together and the
+    // next slab's before the current one is reduced.  Table entries and weights live in registers.
+    const int c = q * 4, p0 = threadIdx.x >> 4;
+    const float4 mu = *reinterpret_cast<const float4*>(s_mean + c);
+    const float4 sc = *reinterpret_cast<const float4*>(s_scale + c);
+    const float4 be = *reinterpret_cast<const float4*>(s_beta + c);
+    float4 wv[4];
+#pragma unroll
+    for (int co = 0; co < 4; ++co) wv[co] = (co < Cout) ? *reinterpret_cast<const float4*>(s_w + co * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* ub = u + ((size_t)n * HW + pixb + p0) * C + c;
+    float4 cur[4], nxt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cur[k] = *reinterpret_cast<const float4*>(ub + (size_t)(16 * k) * C);
+    for (int sl = 0; sl < slabs; ++sl) {
+      const int sn = (sl + 1 < slabs) ? sl + 1 : sl;  // (clamped: the last prefetch re-reads valid data, unused)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) nxt[k] = *reinterpret_cast<const float4*>(ub + (size_t)(sn * 64 + 16 * k) * C);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float4 v = cur[k];
+        v.x = dm_silu((v.x - mu.x) * sc.x + be.x);
+        v.y = dm_silu((v.y - mu.y) * sc.y + be.y);
+        v.z = dm_silu((v.z - mu.z) * sc.z + be.z);
+        v.w = dm_silu((v.w - mu.w) * sc.w + be.w);
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+          if (co < Cout) {
+            float sm = v.x * wv[co].x + v.y * wv[co].y + v.z * wv[co].z + v.w * wv[co].w;
+            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            if (q == 0) out[((size_t)n * Cout + co) * HW + pixb + sl * 64 + p0 + 16 * k] = sm + bias[co];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+    }
+    return;
+  }
   for (int sl = 0; sl < slabs; ++sl) {
   const int pix0 = pixb + sl * 64;
   for (int pp = threadIdx.x / LP; pp < 64; pp += ppp) {
