@@ -83,3 +83,15 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 1, 32, 32), torch.tensor(0))
     with pytest.raises(RuntimeError, match="GPU"):
         d.DDPMScheduler().step(torch.zeros(1, 1, 32, 32), 0, torch.zeros(1, 1, 32, 32))
+
+
+def test_bench_kernel_class_names_match_header_enum():
+    """bench.py indexes dm_unet_profile's arrays by the DM_K_* enum of include/dm_sampler.h."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "dm_sampler.h")).read()
+    enum = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"(DM_K_[A-Z0-9_]+)\s*=\s*(\d+)", hdr))
+    src = open(os.path.join(root, "bench.py")).read()
+    names = re.search(r"K_NAMES = \[(.*?)\]", src, re.S).group(1).count('"') // 2
+    assert names == enum["DM_K_COUNT"]
+    assert enum["DM_K_WINO"] == 10 and "10  # dominant" in src.replace("else 10", "10")
