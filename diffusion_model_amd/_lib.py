@@ -30,6 +30,9 @@ _SIGS = {
     "dm_sampler_step": (_i, [_vp, _vp, _vp, C.POINTER(_f), _vp, _sz, _vp]),
     "dm_sampler_coefs": (_i, [_vp, _vp, _vp, _i, _vp, _i, _f, _vp]),
     "dm_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _sz, _i, _vp]),
+    "dm_sample_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
+    "dm_sampler_step_batched": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
+    "dm_final_conv": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dm_postprocess": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "dm_class_embed": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dm_unet_profile": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_f), _i, _i, _i, _vp, _sz, _i, _vp,

@@ -2,9 +2,11 @@
 
 The reference defines the module but wires it to nothing; how it enters the UNet
 and classifier-free guidance are BUILD-DEFINED (parity unpinned, oracle = oracle/unet_oracle.py
-``cfg_eps``): the class embedding is added to the time embedding, the null class is the extra
-row ``num_classes`` of an ``nn.Embedding(num_classes + 1, E)``, and guidance combines
-eps = eps_u + w (eps_c - eps_u) on the doubled batch.
+``cfg_eps``): the class embedding is added to the time embedding and guidance combines
+eps = eps_u + w (eps_c - eps_u) on the doubled batch.  The module itself is the reference's:
+``nn.Embedding(num_classes, E)``, labels in [0, num_classes).  A caller that wants a null class
+for guidance constructs it with ONE MORE row (``ClassConditioner(10 + 1)`` for ten digits) and
+uses label ``10`` as the null label; nothing here reserves that row.
 """
 import torch
 import torch.nn as nn
@@ -38,6 +40,8 @@ class ClassConditioner(nn.Module):
         if lab.numel() and (int(lab.min()) < 0 or int(lab.max()) >= self.num_classes):
             raise IndexError("index out of range in self")  # what nn.Embedding raises
         out = torch.empty((lab.numel(), self.embedding_dim), dtype=torch.float32, device=tbl.device)
+        if lab.numel() == 0:  # the reference returns an empty [0, E] tensor
+            return out
         p = self.projection
         _lib.check(_lib.lib().dm_class_embed(
             _lib.ptr(tbl.contiguous()), self.num_classes, self.embedding_dim,

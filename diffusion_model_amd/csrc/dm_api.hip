@@ -40,6 +40,24 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+// Per-device facts, looked up once per device ordinal (function attributes and the CU count are
+// per device: a process may run models on several GPUs).
+constexpr int DM_MAX_DEVICES = 64;
+inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= DM_MAX_DEVICES) d = 0;
+  return d;
+}
+inline unsigned cu_count(int dev) {
+  static int cus[DM_MAX_DEVICES] = {0};
+  if (cus[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev] = v;
+  }
+  return (unsigned)cus[dev];
+}
+
 // ------------------------------------------------------------------ per-launch profiler
 // dm_unet_profile brackets every launch of one forward with hipEvents (on the launch stream)
 // and books its algorithmic FLOPs / bytes per kernel class; inactive otherwise.
@@ -114,6 +132,7 @@ struct ConvCall {
   const float* temb; int temb_stride; int temb_step_stride;
   const int* step_ptr; int step_off;
   float* y; float* stats_out;
+  size_t stats_cap;  // floats available behind stats_out (0 = caller-sized, unchecked)
   int B, H, W;
   const float* res; int no_silu;
   int bf16;  // activations and packed weights are bf16 (conv_bf16_kernel)
@@ -122,11 +141,12 @@ struct ConvCall {
 
 template <int MB, int KIND, int KC, int GEO = 0>
 int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr_done = false;  // benign race: setting the attribute twice is harmless
-  if (!attr_done) {
+  static bool attr_done[DM_MAX_DEVICES] = {false};  // per device; benign race: setting the attribute twice is harmless
+  const int dev = current_device();
+  if (!attr_done[dev]) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<MB, KIND, KC, GEO>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    attr_done[dev] = true;
   }
   constexpr bool UP = (KIND == 2 || KIND == 4);
   const int cls = KIND == 5 ? DM_K_WINO : KIND == 0 ? (MB == 2 ? DM_K_CONV3_128 : DM_K_CONV3_64)
@@ -144,11 +164,12 @@ int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
 
 template <int MB, int KIND>
 int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[DM_MAX_DEVICES] = {false};
+  const int dev = current_device();
+  if (!attr_done[dev]) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MB, KIND>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
+    attr_done[dev] = true;
   }
   const int cls = KIND == 0 ? (MB == 2 ? DM_K_CONV3_128 : DM_K_CONV3_64) : KIND == 1 ? DM_K_DOWN : (MB == 2 ? DM_K_UP_128 : DM_K_UP_64);
   const double opix = (double)a.B * a.Hb * a.Wb * (KIND == 2 ? 4 : 1);
@@ -175,9 +196,12 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   if (c.stats_in && c.c2) return fail("conv: input transform and channel concat are exclusive");
   if (c.B <= 0) return fail("conv: empty batch");
   ConvGeo g = conv_geo(c.kind, c.H, c.W, c.cout);
+  if (c.stats_out && c.stats_cap && (size_t)c.B * g.pout * DM_GROUPS * 2 > c.stats_cap)
+    return fail("conv: statistics buffer too small (%zu floats for %d images x %d partials)", c.stats_cap, c.B, g.pout);
   // transposed conv with a single K chunk: all four output parities from one staged tile
   if (c.bf16 && (c.kind == 3 || c.res)) return fail("conv: the bf16 path has no 1x1 / residual variant");
-  const bool fused_up = c.kind == 2 && cin == 64 && !c.bf16;
+  // (not below 4x4 input pixels: the tiny-image statistics path needs the staged output tile)
+  const bool fused_up = c.kind == 2 && cin == 64 && !c.bf16 && g.Hb * g.Wb >= 16;
   if (fused_up) { g.hth += 1; g.htw += 1; }
   ConvArgs a;
   memset(&a, 0, sizeof a);
@@ -199,21 +223,27 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   a.tpi_log = ilog2(g.tiles_per_img); a.tx_log = ilog2(g.tiles_x);
   a.g_log = is_pow2(c.cout) ? ilog2(c.cout / DM_GROUPS) : 3;  // (only read when statistics are requested: Cout in {64..512})
   a.g1_log = ilog2(c.c1 / DM_GROUPS);
-  {
-    const int ppp = c.kind == 6 ? 64 : (c.bf16 || c.kind == 1) ? 32 : 16;  // 256 threads / (16-byte loads per pixel per chunk)
-    a.ppp_q = ppp / g.htw; a.ppp_r = ppp % g.htw;
-  }
   a.init_x = c.init_x; a.init_w = c.init_w; a.init_b = c.init_b; a.init_cin = c.init_cin;
   if (c.init_x && ((c.kind != 0 && c.kind != 5) || c.stats_in || c.c2)) return fail("conv: folded init_conv needs a plain 3x3 conv");
   const size_t init_f = c.init_x ? (size_t)g.ni * c.init_cin * (g.hth + 2) * (g.htw + 2) + 4 + (size_t)c.init_cin * 9 * 64 + 64 + 8 : 0;
 #ifdef DM_STAMPS
   a.stamps = g_stamps;
 #endif
-  const int kc = (c.kind == 6) ? 16 : (c.kind == 1) ? 32 : 64;
   const size_t np = (size_t)g.ni * g.hth * g.htw;
-  size_t lds_f = np * (kc + 4) + (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (fused_up ? 128 : 0) + init_f;
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
-  if (lds_f < epi_f) lds_f = epi_f;
+  auto lds_floats = [&](int kc_) {
+    const size_t f = np * (kc_ + 4) + (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (fused_up ? 128 : 0) + init_f;
+    return f < epi_f ? epi_f : f;
+  };
+  int kc = (c.kind == 6) ? 16 : (c.kind == 1) ? 32 : 64;  // K chunk (input channels staged at a time)
+  // Images below 4x4 pixels ride 16-64 to a tile, each with its own halo: halve the K chunk when the halo tile
+  // would not fit the CU's LDS (the deepest levels of 8x8 / 16x16 models)
+  if (!c.bf16 && !c.init_x && g.MT == 64 && (c.kind == 0 || c.kind == 1) && lds_floats(kc) * sizeof(float) > 160 * 1024) kc /= 2;
+  {
+    const int ppp = c.bf16 ? 32 : 256 / (kc / 4);  // 256 threads / (16-byte loads per pixel per chunk)
+    a.ppp_q = ppp / g.htw; a.ppp_r = ppp % g.htw;
+  }
+  size_t lds_f = lds_floats(kc);
   if (c.kind == 5) {
     if (lds_f < DM_WINO_EPI_FLOATS) lds_f = DM_WINO_EPI_FLOATS;
     lds_f += 208;  // staging descriptor table
@@ -231,7 +261,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), (c.kind == 2 && !fused_up) ? 4u : 1u);
   a.ntiles = (int)grid.x;
   if (!c.bf16) {  // persistent fp32 kernel: at most 3 (Winograd: 2) resident workgroups per CU (256 CUs)
-    const unsigned slots = c.kind == 5 ? 512u : 768u;  // (measured: 512 vs 768 slots for the direct kernels is a wash)
+    const unsigned slots = (c.kind == 5 ? 2u : 3u) * cu_count(current_device());  // (measured: 2 vs 3 per CU for the direct kernels is a wash)
     const unsigned resident = slots / (grid.y * grid.z) ? slots / (grid.y * grid.z) : 1u;
     if (grid.x > resident) grid.x = resident;
     a.ngroups = groups;
@@ -254,6 +284,8 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   if (fused_up && g.MT == 128 && c64 && c.c2 == 0 && g.th_log == 3 && g.tw_log == 4) return launch_conv_t<2, 4, 64, 1>(a, grid, lds, s);
   if (fused_up) return g.MT == 128 ? launch_conv_t<2, 4, 64>(a, grid, lds, s) : launch_conv_t<1, 4, 64>(a, grid, lds, s);
   (void)cin;
+  if (c.kind == 0 && kc == 32) return launch_conv_t<1, 0, 32>(a, grid, lds, s);
+  if (c.kind == 1 && kc == 16) return launch_conv_t<1, 1, 16>(a, grid, lds, s);
   if (c.kind == 0) return g.MT == 128 ? launch_conv_t<2, 0, 64>(a, grid, lds, s) : launch_conv_t<1, 0, 64>(a, grid, lds, s);
   if (c.kind == 2) return g.MT == 128 ? launch_conv_t<2, 2, 64>(a, grid, lds, s) : launch_conv_t<1, 2, 64>(a, grid, lds, s);
   if (c.kind == 3) return g.MT == 128 ? launch_conv_t<2, 3, 64>(a, grid, lds, s) : launch_conv_t<1, 3, 64>(a, grid, lds, s);
@@ -288,9 +320,12 @@ int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream
 // ------------------------------------------------------------------ model container
 struct BlockOff { size_t tmw, tmb, c1, c1b, c2, c2b, tr, trb, g1, b1, g2, b2, c1w, c2w; };  // c1w/c2w: Winograd form
 
+// A captured chunk of S sampling steps.  The nodes hold workspace addresses only (dm_sample stages
+// x, timesteps, coefficients, class embeddings and noise into the workspace), so the key is the
+// workspace, the weights and everything the carve layout / launch sequence depends on.
 struct GraphEntry {
-  const void *packed, *x, *ws, *coefs, *noise, *cond;
-  int B, H, W, S, cfg;
+  const void *packed, *ws;
+  int B, H, W, S, n, cfg, noise, bf16;
   float guidance;
   hipGraph_t graph;
   hipGraphExec_t exec;
@@ -314,12 +349,38 @@ namespace {
 
 struct Workspace {
   float *A0, *T1, *T2, *D1, *D2, *D3, *BT0, *BT, *U1, *U2, *SA, *SB, *heads, *temb, *eps, *xx;
+  float *xcur, *coefs, *cond, *noise;  // dm_sample's staged operands (graph nodes only see workspace addresses)
+  int64_t* ts;
   int* step;
+  size_t stats_floats;  // capacity of SA and of SB
   size_t bytes;
 };
 
-// Carve the workspace for a denoiser batch B (all offsets 256-B aligned).
-Workspace carve(const dm_unet* m, void* base, int B, int H, int W, int nsteps) {
+// Largest number of GroupNorm partials per image that any layer of the launch sequence writes
+// (conv_geo().pout over the 3x3, stride-2 and transposed convs at the four resolutions, both
+// arithmetic variants): the statistics buffers are sized for it.
+size_t max_stats_partials(int H, int W, int C) {
+  int pm = 1;
+  auto upd = [&](int kind, int h, int w) { const int q = conv_geo(kind, h, w, C).pout; if (q > pm) pm = q; };
+  for (int l = 0; l < 4; ++l) {
+    const int h = H >> l, w = W >> l;
+    if (h < 1 || w < 1) break;
+    upd(0, h, w);
+    if (h >= 8 && w >= 8) upd(5, h, w);
+    if (l < 3 && h >= 2 && w >= 2) {
+      upd(1, h, w);
+      if ((h / 2) * (w / 2) >= 128) upd(6, h, w);
+    }
+    if (l >= 1) upd(2, h, w);
+  }
+  return (size_t)pm;
+}
+
+// Carve the workspace for a denoiser batch B (all offsets 256-B aligned).  Everything whose
+// address a captured graph bakes in and whose size does not depend on the number of steps
+// comes first, so those addresses are a function of (B, H, W) only; the step-count-dependent
+// tables follow; `noise_floats` > 0 appends dm_sample's per-chunk noise staging area.
+Workspace carve(const dm_unet* m, void* base, int B, int H, int W, int nsteps, size_t noise_floats = 0) {
   Workspace w;
   size_t off = 0;
   auto take = [&](size_t floats) {
@@ -328,6 +389,11 @@ Workspace carve(const dm_unet* m, void* base, int B, int H, int W, int nsteps) {
     return p;
   };
   const size_t full = (size_t)B * H * W * m->C;
+  w.step = reinterpret_cast<int*>(take(64));
+  w.eps = take((size_t)B * m->Cout * H * W);
+  w.xx = take((size_t)B * m->Cin * H * W);
+  w.xcur = take((size_t)B * m->Cin * H * W);
+  w.cond = take((size_t)B * m->E);
   w.A0 = take(full);  // init_conv output; reused for up3's output (u3)
   w.T1 = take(full);
   w.T2 = take(full);
@@ -338,24 +404,28 @@ Workspace carve(const dm_unet* m, void* base, int B, int H, int W, int nsteps) {
   w.BT = take(full / 64);
   w.U1 = take(full / 16);
   w.U2 = take(full / 4);
-  const size_t pmax = (size_t)H * W / 64 > 1 ? (size_t)H * W / 64 : 1;
-  w.SA = take((size_t)B * pmax * DM_GROUPS * 2);
-  w.SB = take((size_t)B * pmax * DM_GROUPS * 2);
+  w.stats_floats = (size_t)B * max_stats_partials(H, W, m->C) * DM_GROUPS * 2;
+  w.SA = take(w.stats_floats);
+  w.SB = take(w.stats_floats);
   const size_t nt = (size_t)(nsteps > B ? nsteps : B);
   w.heads = take(nt * 6 * m->C);
   w.temb = take(nt * m->E);
-  w.eps = take((size_t)B * m->Cout * H * W);
-  w.xx = take((size_t)B * m->Cin * H * W);
-  w.step = reinterpret_cast<int*>(take(64));
+  w.coefs = take((size_t)nsteps * 8);
+  w.ts = reinterpret_cast<int64_t*>(take((size_t)nsteps * 2));
+  w.noise = noise_floats > 0 ? take(noise_floats) : nullptr;
   w.bytes = off;
   return w;
 }
+
+int launch_final(const float* u, int bf16, const float* stats, int pin, float cnt, const float* gamma, const float* beta,
+                 const float* wt, const float* bias, float* out, int B, int H, int W, int C, int Cout, hipStream_t s);
 
 int check_geometry(const dm_unet* m, int B, int H, int W) {
   if (B <= 0) return fail("batch must be positive (got %d)", B);
   if (!is_pow2(H) || !is_pow2(W) || H < 8 || W < 8)
     return fail("image height/width must be powers of two >= 8 (three 2x down-samplings; got %dx%d)", H, W);
-  (void)m;
+  if (m->bf16 && (H < 16 || W < 16))
+    return fail("the bf16 kernels need image height/width >= 16 (got %dx%d); use fp32 for smaller images", H, W);
   return 0;
 }
 
@@ -449,7 +519,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   auto base = [&](int kind, const float* x1, int c1, const float* x2, int c2, size_t wp, size_t bias, float* y, float* so, int h, int ww) {
     memset(&c, 0, sizeof c);
     c.kind = kind; c.x1 = x1; c.c1 = c1; c.x2 = x2; c.c2 = c2; c.wp = P + wp; c.bias = P + bias; c.cout = C;
-    c.y = y; c.stats_out = so; c.B = B; c.H = h; c.W = ww; c.bf16 = m->bf16;
+    c.y = y; c.stats_out = so; c.stats_cap = w.stats_floats; c.B = B; c.H = h; c.W = ww; c.bf16 = m->bf16;
   };
   auto with_tf = [&](const float* si, int kind_prod, int hp, int wp_, size_t g, size_t b) {
     const ConvGeo pg = conv_geo(kind_prod, hp, wp_, C);
@@ -500,33 +570,38 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   if (block(5, w.U2, w.D1, H / 2, W / 2, true, w.A0, w.SA)) return 1;
   {  // final_conv (model.py:111-115,151)
     const ConvGeo pg = conv_geo(2, H / 2, W / 2, C);
-    const size_t lds = (size_t)(3 * C + m->Cout * C) * sizeof(float);
-    ProfScope ps(DM_K_FINAL, s, 2.0 * B * H * W * C * m->Cout, 4.0 * B * H * W * (C + m->Cout));
-    if (m->bf16) {
-      const int slabs = (H * W / 64) >= 8 ? 8 : (H * W / 64);
-      hipLaunchKernelGGL(final_conv_bf16_kernel, dim3((unsigned)(B * (H * W / 64 / slabs))), dim3(256), lds, s,
-                         reinterpret_cast<const bf16_t*>(w.A0), w.SA, pg.pout, pg.cnt_out, P + m->o_fg, P + m->o_fb,
-                         P + m->o_fw, P + m->o_fwb, eps, B, H * W, C, m->Cout, slabs);
-    }
-    else
-    {
-      const int slabs = (H * W / 64) >= 8 ? 8 : (H * W / 64);  // measured at 32x32, B=1024: 1 -> 96 us, 8 -> 62 us, 16 -> 85 us
-      hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)(B * (H * W / 64 / slabs))), dim3(256), lds, s, w.A0, w.SA, pg.pout,
-                         pg.cnt_out, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H * W, C, m->Cout, slabs);
-    }
-    HIP_TRY(hipGetLastError());
+    if (launch_final(w.A0, m->bf16, w.SA, pg.pout, pg.cnt_out, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H, W,
+                     C, m->Cout, s)) return 1;
   }
   return 0;
 }
 
-int launch_step(const float* x, const float* eps, const float* noise, const float* coefs_dev,
+// final_conv (model.py:111-115,151): GroupNorm + SiLU + 1x1 in one pass over the NHWC activation
+int launch_final(const float* u, int bf16, const float* stats, int pin, float cnt, const float* gamma, const float* beta,
+                 const float* wt, const float* bias, float* out, int B, int H, int W, int C, int Cout, hipStream_t s) {
+  if (H * W % 64) return fail("final_conv: H*W must be a multiple of 64 (got %dx%d)", H, W);
+  const size_t lds = (size_t)(3 * C + Cout * C) * sizeof(float);
+  ProfScope ps(DM_K_FINAL, s, 2.0 * B * H * W * C * Cout, 4.0 * B * H * W * (C + Cout));
+  const int slabs = (H * W / 64) >= 8 ? 8 : (H * W / 64);  // measured at 32x32, B=1024: 1 -> 96 us, 8 -> 62 us, 16 -> 85 us
+  const dim3 grid((unsigned)(B * (H * W / 64 / slabs)));
+  if (bf16)
+    hipLaunchKernelGGL(final_conv_bf16_kernel, grid, dim3(256), lds, s, reinterpret_cast<const bf16_t*>(u), stats, pin, cnt,
+                       gamma, beta, wt, bias, out, B, H * W, C, Cout, slabs);
+  else
+    hipLaunchKernelGGL(final_conv_kernel, grid, dim3(256), lds, s, u, stats, pin, cnt, gamma, beta, wt, bias, out, B, H * W, C,
+                       Cout, slabs);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_step(const float* x, const float* eps, const float* noise, int noise_idx, const float* coefs_dev,
                 const int* step_ptr, int step_off, const float* cbyval, float* out, size_t count,
                 int cfg, float guidance, hipStream_t s) {
   if (count % 4) return fail("sampler_step: element count must be a multiple of 4 (got %zu)", count);
   StepArgs a;
   memset(&a, 0, sizeof a);
   a.x = x; a.eps = eps; a.noise = noise; a.coefs = coefs_dev; a.step_ptr = step_ptr; a.out = out;
-  a.count = count; a.step_off = step_off; a.cfg = cfg; a.guidance = guidance;
+  a.count = count; a.step_off = step_off; a.cfg = cfg; a.guidance = guidance; a.noise_idx = noise_idx;
   if (cbyval) for (int i = 0; i < 5; ++i) a.c[i] = cbyval[i];
   size_t blocks = (count / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -701,7 +776,31 @@ int dm_sampler_step(const float* x, const float* eps, const float* noise, const 
                     float* out, size_t count, void* stream) {
   if (!x || !eps || !coef_host || !out) return fail("dm_sampler_step: null argument");
   if (count == 0) return 0;
-  return launch_step(x, eps, noise, nullptr, nullptr, 0, coef_host, out, count, 0, 0.f, (hipStream_t)stream);
+  return launch_step(x, eps, noise, 0, nullptr, nullptr, 0, coef_host, out, count, 0, 0.f, (hipStream_t)stream);
+}
+
+int dm_sampler_step_batched(const float* x, const float* eps, const float* noise, const float* coefs_dev,
+                            float* out, int B, size_t count_per_image, void* stream) {
+  if (!x || !eps || !coefs_dev || !out) return fail("dm_sampler_step_batched: null argument");
+  if (B <= 0 || count_per_image == 0) return 0;
+  if (count_per_image % 4) return fail("sampler_step: element count per image must be a multiple of 4 (got %zu)", count_per_image);
+  StepArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.eps = eps; a.noise = noise; a.coefs = coefs_dev; a.out = out;
+  a.count = (size_t)B * count_per_image; a.img_count = count_per_image;
+  size_t blocks = (a.count / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int dm_final_conv(const float* u_dev, const float* stats_dev, int pin, float cnt_in, const float* gamma, const float* beta,
+                  const float* w_dev, const float* bias_dev, float* out_dev, int B, int H, int W, int C, int Cout, void* stream) {
+  if (!u_dev || !stats_dev || !gamma || !beta || !w_dev || !bias_dev || !out_dev) return fail("dm_final_conv: null argument");
+  if (B <= 0 || pin <= 0) return fail("dm_final_conv: bad sizes");
+  if (C % 64 || C > 512 || Cout < 1 || Cout > 4) return fail("dm_final_conv: C must be a multiple of 64 (<= 512), Cout in 1..4");
+  return launch_final(u_dev, 0, stats_dev, pin, cnt_in, gamma, beta, w_dev, bias_dev, out_dev, B, H, W, C, Cout, (hipStream_t)stream);
 }
 
 int dm_sampler_coefs(const float* acp, const float* acp_prev, const float* pv, int T,
@@ -722,60 +821,85 @@ int dm_sampler_coefs(const float* acp, const float* acp_prev, const float* pv, i
   return 0;
 }
 
-int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, const int64_t* ts_dev,
-              const float* coefs_dev, int n, const float* noise_dev, const float* cond_dev, float guidance,
+size_t dm_sample_workspace_bytes(const dm_unet* m, int B, int H, int W, int n, int guided, int with_noise) {
+  if (!m || B <= 0 || H <= 0 || W <= 0 || n <= 0) return 0;
+  const int S0 = n < 50 ? n : 50;
+  const size_t count = (size_t)B * m->Cin * H * W;
+  return carve(m, nullptr, guided ? 2 * B : B, H, W, n, with_noise ? (size_t)S0 * count : 0).bytes;
+}
+
+int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, const int64_t* ts,
+              const float* coefs, int n, const float* noise, const float* cond, float guidance,
               void* ws, size_t ws_bytes, int use_graph, void* stream) {
-  if (!m || !packed || !x || !ts_dev || !coefs_dev || !ws) return fail("dm_sample: null argument");
+  if (!m || !packed || !x || !ts || !coefs || !ws) return fail("dm_sample: null argument");
   if (m->Cin != m->Cout) return fail("sampling needs in_channels == out_channels (got %d, %d)", m->Cin, m->Cout);
   if (check_geometry(m, B, H, W)) return 1;
   if (n <= 0) return fail("dm_sample: number of steps must be positive");
-  const int cfg = cond_dev ? 1 : 0;
+  const int cfg = cond ? 1 : 0;
   const int Bd = cfg ? 2 * B : B;  // denoiser batch
-  Workspace w = carve(m, ws, Bd, H, W, n);
-  if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes", ws_bytes, w.bytes);
-  hipStream_t s = (hipStream_t)stream;
+  const int S0 = n < 50 ? n : 50;  // steps per graph (and per noise staging chunk)
   const size_t count = (size_t)B * m->Cin * H * W;
+  Workspace w = carve(m, ws, Bd, H, W, n, noise ? (size_t)S0 * count : 0);
+  if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes (dm_sample_workspace_bytes)", ws_bytes, w.bytes);
+  hipStream_t s = (hipStream_t)stream;
+  // Every operand the step kernels read is staged into the workspace, so a captured graph holds
+  // workspace addresses only and is reusable whatever buffers the next call brings.
+  HIP_TRY(hipMemcpyAsync(w.xcur, x, count * sizeof(float), hipMemcpyDefault, s));
+  HIP_TRY(hipMemcpyAsync(w.ts, ts, (size_t)n * sizeof(int64_t), hipMemcpyDefault, s));
+  HIP_TRY(hipMemcpyAsync(w.coefs, coefs, (size_t)n * 8 * sizeof(float), hipMemcpyDefault, s));
+  if (cfg) HIP_TRY(hipMemcpyAsync(w.cond, cond, (size_t)Bd * m->E * sizeof(float), hipMemcpyDefault, s));
   // Time embeddings of all n steps up front: they depend on t only.  With
   // guidance every image has its own embedding (time + class): computed per step for 2B rows.
-  if (!cfg && launch_time_embed(m, packed, ts_dev, n, nullptr, nullptr, w.heads, s)) return 1;
+  if (!cfg && launch_time_embed(m, packed, w.ts, n, nullptr, nullptr, w.heads, s)) return 1;
   const int hstep = 6 * m->C;
+  float* xc = w.xcur;
 
-  auto one_step = [&](const int* step_ptr, int step_off) -> int {
+  // step index = *step_ptr + step_off (tables); `local` = index into the staged noise chunk
+  auto one_step = [&](const int* step_ptr, int step_off, int local) -> int {
     if (!cfg) {
-      if (unet_body(m, packed, x, w.eps, w.heads, 0, hstep, step_ptr, step_off, w, Bd, H, W, s)) return 1;
-      return launch_step(x, w.eps, noise_dev, coefs_dev, step_ptr, step_off, nullptr, x, count, 0, 0.f, s);
+      if (unet_body(m, packed, xc, w.eps, w.heads, 0, hstep, step_ptr, step_off, w, Bd, H, W, s)) return 1;
+      return launch_step(xc, w.eps, noise ? w.noise : nullptr, local, w.coefs, step_ptr, step_off, nullptr, xc, count, 0, 0.f, s);
     }
     // doubled batch [x;x] with embeddings [cond ; null] (build-defined CFG)
     size_t blocks = (count + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(dup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, w.xx, count);
+    hipLaunchKernelGGL(dup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xc, w.xx, count);
     HIP_TRY(hipGetLastError());
-    if (launch_time_embed(m, packed, ts_dev, Bd, cond_dev, nullptr, w.heads, s, step_ptr, step_off, 0)) return 1;
+    if (launch_time_embed(m, packed, w.ts, Bd, w.cond, nullptr, w.heads, s, step_ptr, step_off, 0)) return 1;
     if (unet_body(m, packed, w.xx, w.eps, w.heads, hstep, 0, nullptr, 0, w, Bd, H, W, s)) return 1;
-    return launch_step(x, w.eps, noise_dev, coefs_dev, step_ptr, step_off, nullptr, x, count, 1, guidance, s);
+    return launch_step(xc, w.eps, noise ? w.noise : nullptr, local, w.coefs, step_ptr, step_off, nullptr, xc, count, 1, guidance, s);
+  };
+  // noise of steps [first, first + cnt) -> staging area (noise: [n][count], device or host memory)
+  auto stage_noise = [&](int first, int cnt) -> int {
+    if (!noise) return 0;
+    HIP_TRY(hipMemcpyAsync(w.noise, noise + (size_t)first * count, (size_t)cnt * count * sizeof(float), hipMemcpyDefault, s));
+    return 0;
   };
 
   if (!use_graph) {
-    for (int i = 0; i < n; ++i) if (one_step(nullptr, i)) return 1;
+    for (int i = 0; i < n; ++i) {
+      if (i % S0 == 0 && stage_noise(i, n - i < S0 ? n - i : S0)) return 1;
+      if (one_step(nullptr, i, i % S0)) return 1;
+    }
+    HIP_TRY(hipMemcpyAsync(x, xc, count * sizeof(float), hipMemcpyDefault, s));
     return 0;
   }
   if (!s) return fail("dm_sample: graph capture needs a non-default stream");
   hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(64), 0, s, w.step, 0);
   HIP_TRY(hipGetLastError());
-  const int S0 = n < 50 ? n : 50;
   auto get_graph = [&](int S, hipGraphExec_t* exec) -> int {
     for (auto& g : m->graphs)
-      if (g.packed == packed && g.x == x && g.ws == ws && g.coefs == coefs_dev && g.noise == noise_dev &&
-          g.cond == cond_dev && g.B == B && g.H == H && g.W == W && g.S == S && g.cfg == cfg && g.guidance == guidance) {
+      if (g.packed == packed && g.ws == ws && g.B == B && g.H == H && g.W == W && g.S == S && g.n == n &&
+          g.cfg == cfg && g.noise == (noise ? 1 : 0) && g.guidance == guidance && g.bf16 == m->bf16) {
         *exec = g.exec;
         return 0;
       }
     GraphEntry e;
-    e.packed = packed; e.x = x; e.ws = ws; e.coefs = coefs_dev; e.noise = noise_dev; e.cond = cond_dev;
-    e.B = B; e.H = H; e.W = W; e.S = S; e.cfg = cfg; e.guidance = guidance;
+    e.packed = packed; e.ws = ws; e.B = B; e.H = H; e.W = W; e.S = S; e.n = n; e.cfg = cfg; e.noise = noise ? 1 : 0;
+    e.guidance = guidance; e.bf16 = m->bf16;
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int rc = 0;
-    for (int i = 0; i < S && !rc; ++i) rc = one_step(w.step, i);
+    for (int i = 0; i < S && !rc; ++i) rc = one_step(w.step, i, i);
     if (!rc) {
       hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, w.step, S);
       if (hipGetLastError() != hipSuccess) rc = fail("advance_step launch failed");
@@ -796,12 +920,17 @@ int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, co
   hipGraphExec_t ex;
   if (n / S0 > 0) {
     if (get_graph(S0, &ex)) return 1;
-    for (int r = 0; r < n / S0; ++r) HIP_TRY(hipGraphLaunch(ex, s));
+    for (int r = 0; r < n / S0; ++r) {
+      if (stage_noise(r * S0, S0)) return 1;
+      HIP_TRY(hipGraphLaunch(ex, s));
+    }
   }
   if (n % S0) {
     if (get_graph(n % S0, &ex)) return 1;
+    if (stage_noise(n - n % S0, n % S0)) return 1;
     HIP_TRY(hipGraphLaunch(ex, s));
   }
+  HIP_TRY(hipMemcpyAsync(x, xc, count * sizeof(float), hipMemcpyDefault, s));
   return 0;
 }
 
@@ -822,7 +951,7 @@ int dm_unet_profile(dm_unet* m, const float* packed, float* x, const int64_t* t_
     rc = launch_time_embed(m, packed, t_dev, 1, nullptr, w.temb, w.heads, s);
     if (!rc) rc = unet_body(m, packed, x, w.eps, w.heads, 0, 0, nullptr, 0, w, B, H, W, s);
     // out-of-place (into the workspace) so repeated profiling passes see the same input
-    if (!rc) rc = launch_step(x, w.eps, nullptr, nullptr, nullptr, 0, coef_host, w.xx, (size_t)B * m->Cin * H * W, 0, 0.f, s);
+    if (!rc) rc = launch_step(x, w.eps, nullptr, 0, nullptr, nullptr, 0, coef_host, w.xx, (size_t)B * m->Cin * H * W, 0, 0.f, s);
   }
   g_prof = nullptr;
   hipError_t se = hipStreamSynchronize(s);

@@ -291,6 +291,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
     const int gpt = 1 << gpt_log;                        // groups in this 64-channel tile
     const int rows_log = (p.ni > 1) ? (p.th_log + p.tw_log) : (MB == 2 ? 7 : 6);
     const int rows_img = 1 << rows_log;                  // tile rows that belong to one image
+    if (rows_img < 16) {
+      // Images of fewer than 4x4 base pixels (the deepest levels of 8x8 / 16x16 models): an accumulator
+      // segment would straddle images, so the (mean, M2) pair of every (image, group) is taken from the
+      // staged output tile by one thread each.  Negligible work: these layers hold <= 4 pixels per image.
+      __syncthreads();  // the staged tile is complete
+      const int nig = (MT >> rows_log) << gpt_log;
+      for (int idx = tid; idx < nig; idx += 256) {
+        const int i = idx >> gpt_log, g = idx & (gpt - 1);
+        const int n = img0 + i;
+        if (n < p.B) {
+          auto at = [&](int r, int c) {
+            const int m = (i << rows_log) + r;
+            return BF ? bf2f(reinterpret_cast<const bf16_t*>(otile)[m * 72 + g * G + c]) : otile[m * ORS + g * G + c];
+          };
+          float sm = 0.f;
+          for (int r = 0; r < rows_img; ++r)
+            for (int c = 0; c < G; ++c) sm += at(r, c);
+          const float mu = sm / (float)(rows_img * G);
+          float m2 = 0.f;
+          for (int r = 0; r < rows_img; ++r)
+            for (int c = 0; c < G; ++c) { const float dd = at(r, c) - mu; m2 += dd * dd; }
+          const int pidx = (UP ? par * p.tiles_per_img : 0) + tin;
+          float* so = p.stats_out + (((size_t)n * p.pout + pidx) * DM_GROUPS + blockIdx.y * gpt + g) * 2;
+          so[0] = mu;
+          so[1] = m2;
+        }
+      }
+    } else {
     const bool perseg = rows_img < 32 * MB;              // (then rows_img == 16: one image per segment)
     const int nimg_t = MT >> rows_log;
     const int gg = (lane & 31) >> gl_log;
@@ -353,6 +381,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
       }
       __syncthreads();
     }
+    }  // rows_img >= 16
   } else if (otile) {
     __syncthreads();
   }
@@ -1316,7 +1345,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const TimeArgs a) {
 struct StepArgs {
   const float* x;
   const float* eps;
-  const float* noise;      // null or [*][count]
+  const float* noise;      // null or [*][count]; this launch reads row noise_idx
   const float* coefs;      // null or device table [n][8]
   const int* step_ptr;
   float* out;
@@ -1325,20 +1354,26 @@ struct StepArgs {
   float guidance;
   int cfg;
   int step_off;
+  int noise_idx;
+  size_t img_count;        // > 0: coefs is a per-image table [B][8], img_count elements per image ([B] timesteps)
 };
 
 __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs a) {
 #pragma clang fp contract(off)
   float c0 = a.c[0], c1 = a.c[1], c2 = a.c[2], c3 = a.c[3], c4 = a.c[4];
   const float* nz = a.noise;
-  if (a.coefs) {
+  if (a.coefs && !a.img_count) {
     const int step = (a.step_ptr ? *a.step_ptr : 0) + a.step_off;
     const float* cc = a.coefs + (size_t)step * 8;
     c0 = cc[0]; c1 = cc[1]; c2 = cc[2]; c3 = cc[3]; c4 = cc[4];
-    if (nz) nz += (size_t)step * a.count;
   }
+  if (nz) nz += (size_t)a.noise_idx * a.count;
   const size_t n4 = a.count >> 2;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    if (a.img_count) {  // schedulers.py:113-115 with a [B] timestep tensor: `.view(-1,1,1,1)` coefficients
+      const float* cc = a.coefs + ((i * 4) / a.img_count) * 8;
+      c0 = cc[0]; c1 = cc[1]; c2 = cc[2]; c3 = cc[3]; c4 = cc[4];
+    }
     const float4 x = reinterpret_cast<const float4*>(a.x)[i];
     float4 e = reinterpret_cast<const float4*>(a.eps)[i];
     if (a.cfg) {

@@ -165,14 +165,18 @@ class UNetMini(nn.Module):
                 self._packed = torch.empty(L.dm_unet_packed_floats(h), dtype=torch.float32, device=dev)
             arr = (C.c_void_p * len(ps))(*[p.data_ptr() for p in ps])
             freqs = self.time_mlp[0].frequencies().to(dev)
-            _lib.check(L.dm_unet_pack_weights(h, arr, len(ps), _lib.ptr(freqs), _lib.ptr(self._packed),
-                                              torch.cuda.current_stream(dev).cuda_stream))
+            with torch.cuda.device(dev):
+                _lib.check(L.dm_unet_pack_weights(h, arr, len(ps), _lib.ptr(freqs), _lib.ptr(self._packed),
+                                                  torch.cuda.current_stream(dev).cuda_stream))
             self._pack_key = key
             self._freqs_keepalive = freqs
         return self._packed
 
     def workspace(self, B, H, W, nsteps=1):
-        need = _lib.lib().dm_unet_workspace_bytes(self._native(), B, H, W, nsteps)
+        return self.workspace_bytes(_lib.lib().dm_unet_workspace_bytes(self._native(), B, H, W, nsteps))
+
+    def workspace_bytes(self, need):
+        """Grow-only device workspace of at least ``need`` bytes (the library never allocates)."""
         dev = next(self.parameters()).device
         if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -206,9 +210,10 @@ class UNetMini(nn.Module):
                     raise RuntimeError(f"cond_emb must be [{nt},{self.time_emb_dim}]")
         ws = self.workspace(B, H, W)
         eps = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib().dm_unet_forward(
-            self._native(), _lib.ptr(packed), _lib.ptr(x), _lib.ptr(t), nt, _lib.ptr(cond), _lib.ptr(eps),
-            B, H, W, _lib.ptr(ws), ws.numel(), torch.cuda.current_stream(dev).cuda_stream))
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().dm_unet_forward(
+                self._native(), _lib.ptr(packed), _lib.ptr(x), _lib.ptr(t), nt, _lib.ptr(cond), _lib.ptr(eps),
+                B, H, W, _lib.ptr(ws), ws.numel(), torch.cuda.current_stream(dev).cuda_stream))
         return eps
 
 

@@ -6,6 +6,7 @@ Plotting (``plt.show``) and torchvision are not used: the grid is laid out as
 The reference's broken entry points (``generate_comparison`` passing kwargs that
 ``generate_samples`` does not take; CLI default ``--sampler deterministic``) are made to work
 rather than reproduced."""
+import argparse
 import os
 import struct
 import zlib
@@ -190,3 +191,36 @@ def load_config(config_path):
             except ValueError:
                 config[key] = value
     return config
+
+
+def main(argv=None):
+    """sample.py:323-363 with the same flags.  ``--sampler deterministic`` (the reference's default, which its
+    own ``create_sampler`` rejects: SURVEY F10) is taken as DDIM with eta 0."""
+    ap = argparse.ArgumentParser(description="Generate samples from a trained DDPM (MI355X-native sampler)")
+    ap.add_argument("--checkpoint", type=str, required=True)
+    ap.add_argument("--config", type=str)
+    ap.add_argument("--num-samples", type=int, default=16)
+    ap.add_argument("--sampler", type=str, default="deterministic", choices=["ancestral", "deterministic", "ddim"])
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--eta", type=float, default=1.0)
+    ap.add_argument("--output-dir", type=str, default="samples")
+    ap.add_argument("--comparison", action="store_true")
+    ap.add_argument("--progressive", action="store_true")
+    ap.add_argument("--seed", type=int, default=42)
+    args = ap.parse_args(argv)
+    config = load_config(args.config) if args.config else get_default_config()
+    config["checkpoint_path"] = args.checkpoint
+    config["seed"] = args.seed
+    stype, eta = ("ddim", 0.0) if args.sampler == "deterministic" else (args.sampler, args.eta)
+    drv = DDPMSampler(config, sampler_type=stype, num_inference_steps=args.steps, eta=eta)
+    if args.comparison:
+        drv.generate_comparison(num_samples=args.num_samples, output_dir=args.output_dir)
+    elif args.progressive:
+        drv.generate_progressive(num_samples=args.num_samples, output_dir=args.output_dir, eta=eta,
+                                 num_inference_steps=args.steps)
+    else:
+        drv.generate_and_save(num_samples=args.num_samples, output_dir=args.output_dir)
+
+
+if __name__ == "__main__":
+    main()

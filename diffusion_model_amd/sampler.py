@@ -77,23 +77,35 @@ class _SamplerBase:
                                 self.scheduler.step_coefs(timesteps, self.eta).to(dev))
             self._dev_tables_src = (timesteps, timesteps._version, (dev, float(self.eta)), self.scheduler.alphas_cumprod)
         ts_dev, coefs = self._dev_tables
-        nz = None if noises is None else noises.to(dev, torch.float32).contiguous()
+        # per-step noise [n,B,C,H,W]: handed over where it lives.  A host tensor is staged by the library one
+        # 50-step graph chunk at a time (ancestral-1000 at B=1024 is 4 GB of noise: never resident on the device)
+        nz = None
+        if noises is not None:
+            nz = noises.to(torch.float32).contiguous()
+            if nz.device.type == "cuda" and nz.device != dev:
+                nz = nz.to(dev)
+            if nz.shape != (n,) + tuple(x.shape):
+                raise RuntimeError(f"noises must be [{n},{B},{Cin},{H},{W}], got {tuple(nz.shape)}")
         if cond is not None:
             cond = cond.to(dev, torch.float32).contiguous()
             if cond.shape != (2 * B, model.time_emb_dim):
                 raise RuntimeError(f"cond must be [{2 * B},{model.time_emb_dim}]")
-        ws = model.workspace(B if cond is None else 2 * B, H, W, n)
+        L = _lib.lib()
+        need = L.dm_sample_workspace_bytes(model._native(), B, H, W, n, 0 if cond is None else 1, 0 if nz is None else 1)
+        ws = model.workspace_bytes(need)
         packed = model.packed_weights()
         cur = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            _lib.check(_lib.lib().dm_sample(
+        with torch.cuda.device(dev), torch.cuda.stream(side):
+            _lib.check(L.dm_sample(
                 model._native(), _lib.ptr(packed), _lib.ptr(x), B, H, W, _lib.ptr(ts_dev), _lib.ptr(coefs), n,
                 _lib.ptr(nz), _lib.ptr(cond), float(guidance), _lib.ptr(ws), ws.numel(), 1 if self.use_graph else 0, side.cuda_stream))
+            if nz is not None and nz.device.type != "cuda":
+                side.synchronize()  # the library reads the host noise chunk by chunk on this stream
         cur.wait_stream(side)
         for t_ in (x, ts_dev, coefs, nz, ws, packed, cond):
-            if t_ is not None:
+            if t_ is not None and t_.device.type == "cuda":
                 t_.record_stream(side)
         return x
 

@@ -112,17 +112,36 @@ class DDPMScheduler:
         if n % 4:
             raise RuntimeError("element count must be a multiple of 4")
         cbuf = (C.c_float * 5)(*[float(v) for v in coef[:5]])
-        _lib.check(_lib.lib().dm_sampler_step(_lib.ptr(x), _lib.ptr(e), _lib.ptr(nz), cbuf, _lib.ptr(out), n,
-                                              torch.cuda.current_stream(x.device).cuda_stream))
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().dm_sampler_step(_lib.ptr(x), _lib.ptr(e), _lib.ptr(nz), cbuf, _lib.ptr(out), n,
+                                                  torch.cuda.current_stream(x.device).cuda_stream))
         return out
 
     def _step_per_sample(self, model_output, timestep, sample, eta, noise):
-        # [B] timesteps (schedulers.py:113-115 `.view(-1,1,1,1)`): one launch per image row
-        outs = []
-        for b in range(sample.shape[0]):
-            nz = None if noise is None else noise[b:b + 1]
-            outs.append(self.step(model_output[b:b + 1], int(timestep[b]), sample[b:b + 1], eta, nz))
-        return torch.cat(outs)
+        """[B] timesteps (schedulers.py:113-115: ``.view(-1,1,1,1)`` table lookups): per-image
+        coefficients, ONE launch (dm_sampler_step_batched)."""
+        x = sample.contiguous()
+        e = model_output.contiguous()
+        B = x.shape[0]
+        if timestep.numel() != B:
+            raise RuntimeError(f"timestep must have 1 or {B} elements, got {timestep.numel()}")
+        if x.dtype != torch.float32 or e.dtype != torch.float32 or x.shape != e.shape or x.device != e.device:
+            raise RuntimeError("sampler step expects fp32 tensors of one shape on one device")
+        if x.device.type != "cuda":
+            raise RuntimeError("sampler step runs on the GPU only (no CPU path)")
+        per = x.numel() // B
+        if per % 4:
+            raise RuntimeError("element count per image must be a multiple of 4")
+        coefs = self.step_coefs(timestep, eta).to(x.device)
+        nz = None
+        if eta > 0:
+            nz = torch.randn(x.shape) if noise is None else noise
+            nz = nz.to(x.device, torch.float32).contiguous()
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().dm_sampler_step_batched(_lib.ptr(x), _lib.ptr(e), _lib.ptr(nz), _lib.ptr(coefs), _lib.ptr(out),
+                                                          B, per, torch.cuda.current_stream(x.device).cuda_stream))
+        return out
 
     def scale_model_input(self, sample, timestep: Optional[int] = None):
         """diffusion/schedulers.py:133-138: identity."""

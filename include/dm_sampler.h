@@ -103,18 +103,37 @@ int dm_sampler_coefs(const float* acp_host, const float* acp_prev_host, const fl
 /* ---- whole reverse-diffusion loop: replaces AncestralSampler.__call__ /
  * DDIMSampler.__call__ (diffusion/sampler.py:45-76, 136-172).
  * x_dev [B,Cin,H,W]: x_T on entry, final sample on exit (requires Cin == Cout).
- * timesteps_dev int64[n] (ascending, as DDPMScheduler.set_timesteps produces),
- * coefs_dev float[n][8] (dm_sampler_coefs, uploaded by the caller),
- * noise_dev: NULL (eta == 0) or [n,B,Cin,H,W] host-drawn noise in loop order.
+ * timesteps int64[n] (ascending, as DDPMScheduler.set_timesteps produces),
+ * coefs float[n][8] (dm_sampler_coefs),
+ * noise: NULL (eta == 0) or [n,B,Cin,H,W] host-drawn noise in loop order.
+ * x, timesteps, coefs, cond and noise are COPIED into the workspace on `stream` (hipMemcpyDefault:
+ * each may be a device pointer, or a host pointer - noise is staged 50 steps at a time, so a host
+ * tensor never needs a device copy of all n steps), and the result is copied back to x_dev.  A
+ * captured graph therefore holds workspace addresses only and is reused by every later call with
+ * the same model, workspace and (B, H, W, n, guided, noise or not, guidance).
+ * Workspace size: dm_sample_workspace_bytes.
  * cond_dev / guidance: build-defined classifier-free guidance (cond_dev NULL = off):
  *   cond_dev [2B,E] = embeddings for [labels ; null label]; the denoiser runs on the doubled
  *   batch and eps = eps_u + guidance*(eps_c - eps_u).
  * use_graph != 0: the step loop is captured once into a hipGraph (chunks of <= 50 steps
  * that read a device-side step counter) and replayed; 0: eager launches on `stream`. */
 int dm_sample(dm_unet* m, const float* packed_dev, float* x_dev, int B, int H, int W,
-              const int64_t* timesteps_dev, const float* coefs_dev, int n,
-              const float* noise_dev, const float* cond_dev, float guidance,
+              const int64_t* timesteps, const float* coefs, int n,
+              const float* noise, const float* cond, float guidance,
               void* workspace_dev, size_t workspace_bytes, int use_graph, void* stream);
+
+/* Workspace bytes dm_sample needs: dm_unet_workspace_bytes for the (doubled when `guided`) batch
+ * and an n-step table, plus the staging area for one graph chunk of noise when `with_noise`. */
+size_t dm_sample_workspace_bytes(const dm_unet* m, int B, int H, int W, int n, int guided,
+                                 int with_noise);
+
+/* DDPMScheduler.step with a [B] timestep tensor (diffusion/schedulers.py:113-115: the table
+ * lookups become `.view(-1,1,1,1)` per-image coefficients) in ONE launch: coefs_dev float[B][8]
+ * (dm_sampler_coefs rows, uploaded), count_per_image = C*H*W elements; noise_dev NULL or
+ * [B*count_per_image]. */
+int dm_sampler_step_batched(const float* x_dev, const float* eps_dev, const float* noise_dev,
+                            const float* coefs_dev, float* out_dev, int B, size_t count_per_image,
+                            void* stream);
 
 /* ---- post-processing: replaces `(samples + 1) / 2; clamp(0, 1)` (diffusion/sample.py:117-119).
  * out_f32_dev and/or out_u8_dev (uint8 = trunc(v*255 + 0.5), torchvision save_image's rule);
@@ -170,6 +189,12 @@ int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* 
  * [B][pout][8][2] partial statistics of y (pout as dm_conv_stats_partials reports).
  * H, W are the INPUT spatial dims. */
 int dm_conv_stats_partials(int kind, int H, int W);
+/* final_conv (model.py:111-115,151): out[B,Cout,H,W] (NCHW) = Conv1x1(SiLU(GroupNorm8(u))), u NHWC
+ * [B,H,W,C] with statistics partials as above; w [Cout,C], bias [Cout]. */
+int dm_final_conv(const float* u_dev, const float* stats_dev, int pin, float cnt_in,
+                  const float* gamma_dev, const float* beta_dev, const float* w_dev,
+                  const float* bias_dev, float* out_dev, int B, int H, int W, int C, int Cout,
+                  void* stream);
 int dm_conv2d(int kind, const float* x1_dev, int c1, const float* x2_dev, int c2,
               const float* packed_w_dev, const float* bias_dev, int cout,
               const float* stats_in_dev, int pin, float cnt_in, const float* gamma_dev,
