@@ -33,6 +33,9 @@ _SIGS = {
     "dm_sample_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
     "dm_sampler_step_batched": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "dm_final_conv": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "dm_init": (_i, []),
+    "dm_noalloc_scratch_bytes": (_sz, []),
+    "dm_unet_forward_noalloc": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "dm_postprocess": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "dm_class_embed": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dm_unet_profile": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_f), _i, _i, _i, _vp, _sz, _i, _vp,

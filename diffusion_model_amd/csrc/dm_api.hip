@@ -614,8 +614,58 @@ int launch_step(const float* x, const float* eps, const float* noise, int noise_
 
 }  // namespace
 
+// ------------------------------------------------------------------ static scratch (dm_unet_forward_noalloc)
+// One file-scope device array per GPU the library runs on, held until the process ends: the
+// workspace of the entry point that may not allocate.  Host code never uses the array's name as
+// an address: the per-device address comes from hipGetSymbolAddress (noalloc_scratch()).
+static __device__ __align__(256) unsigned char scratch[DM_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+void* g_scratch_ptr[DM_MAX_DEVICES] = {nullptr};
+
+// Address of THIS device's copy of `scratch` (looked up once per device, with that device current).
+int noalloc_scratch(void** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= DM_MAX_DEVICES) return fail("device ordinal %d out of range", dev);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail("hipGetSymbolAddress returned a null address for the static scratch");
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+}  // namespace
+
 // ================================================================== C ABI
 extern "C" {
+
+int dm_init(void) {
+  void* p = nullptr;
+  return noalloc_scratch(&p);
+}
+
+size_t dm_noalloc_scratch_bytes(void) { return (size_t)DM_NOALLOC_SCRATCH_BYTES; }
+
+int dm_unet_forward_noalloc(dm_unet* m, const float* packed, const float* x, const int64_t* t_dev, int nt,
+                            const float* cond_dev, float* eps, int B, int H, int W, void* stream) {
+  if (!m || !packed || !x || !t_dev || !eps) return fail("dm_unet_forward_noalloc: null argument");
+  if (check_geometry(m, B, H, W)) return 1;
+  if (nt != 1 && nt != B) return fail("timesteps must be 0-dim/[1] or [B] (got %d for batch %d)", nt, B);
+  const size_t need = carve(m, nullptr, B, H, W, 1).bytes;
+  if (need > (size_t)DM_NOALLOC_SCRATCH_BYTES)
+    return fail("dm_unet_forward_noalloc: batch %d of %dx%d needs %zu B of scratch, the static buffer holds %zu B; "
+                "use dm_unet_forward with a caller-owned workspace", B, H, W, need, (size_t)DM_NOALLOC_SCRATCH_BYTES);
+  void* base = nullptr;
+  if (noalloc_scratch(&base)) return 1;
+  // every workspace region is written by this call before it is read: nothing has to start at zero
+  Workspace w = carve(m, base, B, H, W, 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (launch_time_embed(m, packed, t_dev, nt, cond_dev, w.temb, w.heads, s)) return 1;
+  return unet_body(m, packed, x, eps, w.heads, nt == 1 ? 0 : 6 * m->C, 0, nullptr, 0, w, B, H, W, s);
+}
 
 const char* dm_last_error(void) { return g_err.c_str(); }
 int dm_version(void) { return 1; }

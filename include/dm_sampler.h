@@ -80,6 +80,22 @@ int dm_unet_forward(dm_unet* m, const float* packed_dev, const float* x_dev,
                     int B, int H, int W, void* workspace_dev, size_t workspace_bytes,
                     void* stream);
 
+/* ---- dm_unet_forward for callers that cannot allocate (NO counterpart in the reference).
+ * For code under hipGraph capture, tight serving loops and harnesses that forbid hipMalloc: the
+ * same forward as dm_unet_forward with the workspace taken from a file-scope device array of
+ * DM_NOALLOC_SCRATCH_BYTES that the library holds on every GPU it runs on until the process ends.
+ * Calls no hipMalloc/hipFree or other allocating routine.  Requests whose workspace exceeds the
+ * array (it holds about 68 images of 32x32 at C=64) are rejected with an error.  All calls on one GPU
+ * share that GPU's array: calls that overlap on one GPU (two streams, two threads) race.
+ * dm_init() performs the one-time per-device set-up (hipGetSymbolAddress) for the CURRENT
+ * device; call it before capture starts - otherwise the first call on a device does it. */
+#define DM_NOALLOC_SCRATCH_BYTES (64u << 20)
+int dm_init(void);
+size_t dm_noalloc_scratch_bytes(void);
+int dm_unet_forward_noalloc(dm_unet* m, const float* packed_dev, const float* x_dev,
+                            const int64_t* t_dev, int nt, const float* cond_dev, float* eps_dev,
+                            int B, int H, int W, void* stream);
+
 /* ---- time embedding: replaces SinusoidalPositionEmbeddings.forward + UNetMini.time_mlp +
  * the six Block.time_mlp heads (diffusion/model.py:18-30, 82-87, 56).
  * temb_dev [nt,E] (may be NULL), heads_dev [nt,6,C] = SiLU(Linear_k(temb)). */

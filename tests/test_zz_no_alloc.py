@@ -1,0 +1,58 @@
+"""dm_unet_forward_noalloc (no counterpart in the reference): the forward for callers that cannot
+allocate, on the library's file-scope device scratch array, against dm_unet_forward on a caller-owned
+workspace — bit for bit, two calls in a row, the second with a smaller input."""
+import ctypes as C
+
+import pytest
+import torch
+
+import diffusion_model_amd as d
+from diffusion_model_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _fwd_noalloc(m, x, t, eps, cond=None):
+    L = _lib.lib()
+    B, _, H, W = x.shape
+    eps.fill_(float("nan"))
+    _lib.check(L.dm_unet_forward_noalloc(m._native(), _lib.ptr(m.packed_weights()), _lib.ptr(x), _lib.ptr(t), t.numel(),
+                                         _lib.ptr(cond), _lib.ptr(eps), B, H, W, torch.cuda.current_stream().cuda_stream))
+    return eps
+
+
+def test_noalloc_forward_matches_workspace_forward(sd):
+    L = _lib.lib()
+    m = d.UNetMini(image_size=32).eval()
+    m.load_state_dict(sd)
+    _lib.check(L.dm_init())
+    assert L.dm_noalloc_scratch_bytes() == 64 << 20
+    g = torch.Generator().manual_seed(123)
+    x1 = torch.randn((24, 1, 32, 32), generator=g).to(DEV)
+    x2 = torch.randn((5, 1, 32, 32), generator=g).to(DEV)
+    t1 = torch.tensor([500], device=DEV)
+    t2 = torch.randint(0, 1000, (5,), generator=g).to(DEV)  # [B] timesteps on the second, smaller call
+    ref1 = m(x1, t1)
+    ref2 = m(x2, t2)
+    e1, e2, e3 = torch.empty_like(ref1), torch.empty_like(ref2), torch.empty_like(ref1)  # outputs are the caller's
+    # warm-up outside the measured window: first launches load code objects (the harness's fill kernel included)
+    _fwd_noalloc(m, x2[:1].contiguous(), t1, torch.empty_like(ref2[:1]))
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    a1 = _fwd_noalloc(m, x1, t1, e1)
+    a2 = _fwd_noalloc(m, x2, t2, e2)  # smaller input right after: the array keeps the first call's contents
+    a3 = _fwd_noalloc(m, x1, t1, e3)  # and the large one once more (shrinking and growing again)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free1 >= free0 - (1 << 20), (free0, free1)  # no device memory was taken by the calls
+    assert torch.equal(a1, ref1)
+    assert torch.equal(a2, ref2)
+    assert torch.equal(a3, ref1)
+    assert torch.isfinite(a1).all() and torch.isfinite(a2).all()
+    # sizes beyond the static array are rejected with a clear error
+    big = torch.zeros((128, 1, 32, 32), device=DEV)
+    eps = torch.empty_like(big)
+    rc = L.dm_unet_forward_noalloc(m._native(), _lib.ptr(m.packed_weights()), _lib.ptr(big), _lib.ptr(t1), 1, None,
+                                   _lib.ptr(eps), 128, 32, 32, torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and b"static buffer" in L.dm_last_error()
