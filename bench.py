@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — sampled images/s of the MI355X-native DDIM-50 sampler (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--total-images T]
 
 A "step" is ONE full DDIM-50 sampling pass (50 denoiser evaluations + 50 sampler updates) over
 one batch of B=1024 synthetic 32x32 images per GPU (BASELINE.json configs[1]); x_T and the
 weights are resident in HBM when the timed region starts.  N>1 is launched by the driver with
 torch.distributed.run, one rank per GPU: every rank samples its own B images (weak scaling,
 no data-path collective inside the loop) and the finished samples are all-gathered over
-RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+RCCL inside the timed region.  `--total-images T` instead fixes the whole job at T images
+(BASELINE configs[2]: 65536) and gives every rank T/N of them (strong scaling).
+Rank 0 prints ONE JSON line.
 
 Extra legs on rank 0 at N=1 (outside the timed region):
   roofline     — dm_unet_profile: hipEvent pairs around every kernel launch of the denoiser on
-                 the launch stream; the dominant kernel class is the 3x3 implicit-GEMM conv.
-  cpu_baseline — the CPU oracle (oracle/unet_oracle.py, kind "port") on a bounded sample.
+                 the launch stream; the dominant kernel class is the Winograd 3x3 conv.
+                 `frac` is the EXECUTED MFMA fraction of the fp32-MFMA peak (the Winograd form
+                 executes 4/9 of the direct-conv FLOPs); `algorithmic_frac` prices the
+                 algorithmic direct-conv FLOPs and may exceed 1.
+  end_to_end   — the same pass with the x_T upload (H2D) and the sample download (D2H) inside the
+                 timed region, next to the resident number (`value`).
+  configs      — short runs of the other BASELINE.json configurations (cfg1 ancestral-1000 B=64,
+                 cfg3's per-GPU shard B=8192, cfg4 bf16 + guidance, cfg5 64x64x3 C=256 with and
+                 without attention), each with images/s, its dominant kernel class with the
+                 executed fraction, and a CPU-oracle check on a small slice.
+  cpu_baseline — the CPU oracle (oracle/unet_oracle.py, kind "port") on a bounded sample; its
+                 output also checks the GPU samples.
 """
 import argparse
 import ctypes as C
@@ -29,9 +41,173 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_IMAGE_STEP = 364_249_088  # SURVEY 8(d), equals torch.utils.flop_counter on model.py:120-151
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA peak
+PEAK_HBM_GBPS = 8000.0
 K_NAMES = ["init_conv", "conv3x3_mfma_t128", "conv3x3_mfma_t64", "conv4x4s2_mfma", "convT4x4s2_mfma_t128",
            "convT4x4s2_mfma_t64", "final_conv", "time_embed", "sampler_step", "attention", "conv3x3_winograd_mfma"]
 NK = len(K_NAMES)  # DM_K_COUNT
+K_WINO = 10
+MFMA_CLASSES = (1, 2, 3, 4, 5, 9, 10)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_traffic.json")  # PMC passes of this round's build (profiles/README.md)
+
+
+def flop_per_image_step(C_, S, cin, cout):
+    """SURVEY 8(a) closed form: MACs/img = 43.265625 C^2 S + 9 Cin C S + C Cout S."""
+    return 2.0 * (43.265625 * C_ * C_ * S + 9.0 * cin * C_ * S + C_ * cout * S)
+
+
+def profile_model(model, sched, B, H, W, reps=3):
+    """Per-kernel-class device time of `reps` denoiser evaluations (dm_unet_profile)."""
+    from diffusion_model_amd import _lib
+    L = _lib.lib()
+    dev = next(model.parameters()).device
+    ws = model.workspace(B, H, W)
+    packed = model.packed_weights()
+    t_dev = torch.tensor([500], device=dev)
+    coef = sched.step_coefs(torch.tensor([500]), 0.0)[0]
+    cbuf = (C.c_float * 5)(*[float(v) for v in coef[:5]])
+    counts, ms = (C.c_int * NK)(), (C.c_float * NK)()
+    fl, by = (C.c_double * NK)(), (C.c_double * NK)()
+    xs = torch.randn((B, model.in_channels, H, W), generator=torch.Generator().manual_seed(1)).to(dev)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for r in (1, reps):  # first call warms up
+        _lib.check(L.dm_unet_profile(model._native(), _lib.ptr(packed), _lib.ptr(xs), _lib.ptr(t_dev), cbuf, B, H, W,
+                                     _lib.ptr(ws), ws.numel(), r, side.cuda_stream, counts, ms, fl, by))
+    bf16 = model.precision == "bf16"
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    tot_ms = sum(ms[k] for k in range(NK))
+    per = {}
+    for k in range(NK):
+        if counts[k]:
+            tf = fl[k] / (ms[k] * 1e-3) / 1e12
+            e = {"launches": counts[k] // reps, "avg_us": 1e3 * ms[k] / counts[k], "share": ms[k] / tot_ms, "tflops": tf,
+                 "alg_gbps": by[k] / (ms[k] * 1e-3) / 1e9}
+            if k in MFMA_CLASSES:  # executed MFMA fraction (the Winograd class executes 4/9 of its algorithmic FLOPs)
+                e["executed_mfma_frac"] = tf * (4.0 / 9.0 if k == K_WINO else 1.0) / peak
+            per[K_NAMES[k]] = e
+    raw = {"counts": counts, "ms": ms, "fl": fl, "by": by, "tot_ms": tot_ms}
+    return per, raw
+
+
+def dominant(per):
+    name = max(per, key=lambda k_: per[k_]["share"])
+    e = per[name]
+    return {"kernel": name, "share": e["share"], "avg_us": e["avg_us"], "tflops": e["tflops"],
+            "executed_mfma_frac": e.get("executed_mfma_frac"), "alg_gbps": e["alg_gbps"]}
+
+
+def timed_passes(fn, passes, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / passes, out
+
+
+def run_configs(d, O, dev, sd32):
+    """Short, bounded runs of BASELINE.json's other configurations on ONE GPU."""
+    res = {}
+    sched = d.DDPMScheduler()
+    osch = O.make_schedule()
+
+    # ---- cfg1: DDPM ancestral T=1000, batch 64, eta=1, fp32 (configs[0])
+    m32 = d.UNetMini(image_size=32).eval()
+    m32.load_state_dict(sd32)
+    B, n = 64, 1000
+    smp = d.AncestralSampler(sched, num_inference_steps=n, eta=1.0)
+    g = torch.Generator().manual_seed(11)
+    x_T = torch.randn((B, 1, 32, 32), generator=g)
+    nz = torch.randn((n, B, 1, 32, 32), generator=g).pin_memory()  # host noise, staged 50 steps at a time
+    xd = x_T.to(dev)
+    dt, _ = timed_passes(lambda: smp.sample_from(m32, xd, nz), 2)
+    per, _ = profile_model(m32, sched, B, 32, 32)
+    # oracle check on the first 100 of the 1000 steps, 4 images (the free-running 1000-step chain on random weights
+    # grows to |x| ~ 800 and is ill-conditioned: SURVEY 7)
+    k, ns = 4, 100
+    full_ts = sched.timesteps
+    sched.timesteps = full_ts[:ns]
+    got = smp.sample_from(m32, x_T[:k].contiguous(), nz[:ns, :k].contiguous()).cpu()
+    sched.timesteps = full_ts
+    xr = x_T[:k].clone()
+    with torch.no_grad():
+        for i in range(ns):
+            t = torch.tensor(i)
+            xr = O.sampler_step(osch, O.unet_forward(sd32, xr, t), t, xr, 1.0, nz[i, :k])
+    res["cfg1_ancestral1000_b64_eta1_fp32"] = {
+        "images_per_s": B / dt, "ms_per_pass": 1e3 * dt, "batch": B, "steps": n, "noise": "host tensor, staged per 50-step graph chunk",
+        "frac_fp32_mfma_peak_whole_path_algorithmic": B / dt * n * FLOP_PER_IMAGE_STEP / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        "dominant": dominant(per),
+        "check_max_abs_vs_cpu_oracle": (got - xr).abs().max().item(), "check": f"first {ns} steps, {k} images, |ref|max {xr.abs().max().item():.3g}"}
+    del nz
+
+    # ---- cfg3 shard: DDIM-50, 8192 images on one GPU (= 65536 / 8), fp32 (configs[2])
+    B, n = 8192, 50
+    smp = d.DDIMSampler(sched, num_inference_steps=n, eta=0.0)
+    x_T = torch.randn((B, 1, 32, 32), generator=torch.Generator().manual_seed(12))
+    xd = x_T.to(dev)
+    dt, out = timed_passes(lambda: smp.sample_from(m32, xd), 2)
+    k = 8  # the LAST images of the shard: every persistent kernel has walked all its tiles by then
+    ref = O.sample(sd32, osch, (k, 1, 32, 32), n, 0.0, x_T=x_T[-k:])
+    res["cfg3_shard_ddim50_b8192_fp32"] = {
+        "images_per_s": B / dt, "ms_per_pass": 1e3 * dt, "batch": B, "steps": n,
+        "frac_fp32_mfma_peak_whole_path_algorithmic": B / dt * n * FLOP_PER_IMAGE_STEP / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        "check_max_abs_vs_cpu_oracle": (out[-k:].cpu() - ref).abs().max().item(), "check": f"last {k} images of the shard, all {n} steps",
+        "note": "strong-scaling form: python -m torch.distributed.run ... bench.py --gpus N --total-images 65536"}
+    del out, xd
+    m32._ws = None
+    torch.cuda.empty_cache()
+
+    # ---- cfg4: class-conditional + classifier-free guidance (doubled batch), bf16 (configs[3]; build-defined semantics)
+    B, n, w = 1024, 50, 3.0
+    mb = d.UNetMini(image_size=32, precision="bf16").eval()
+    mb.load_state_dict(sd32)
+    d.set_seed(43)
+    cc = d.ClassConditioner(11, 128)
+    labels = torch.arange(B) % 10
+    cond, null = cc(labels), cc(torch.tensor([10]))
+    x_T = torch.randn((B, 1, 32, 32), generator=torch.Generator().manual_seed(13))
+    xd = x_T.to(dev)
+    smp = d.DDIMSampler(sched, num_inference_steps=n, eta=0.0)
+    dt, out = timed_passes(lambda: smp.sample_from(mb, xd, cond_emb=cond, null_emb=null, guidance_scale=w), 3)
+    per, _ = profile_model(mb, sched, 2 * B, 32, 32)
+    k = 4
+    cd = {k_: v.detach().cpu() for k_, v in cc.state_dict().items()}
+    ref = O.cfg_sample(sd32, cd, osch, x_T[:k], labels[:k], 10, w, n)
+    res["cfg4_classcond_cfg_bf16_b1024"] = {
+        "images_per_s": B / dt, "ms_per_pass": 1e3 * dt, "batch": B, "denoiser_batch": 2 * B, "steps": n, "guidance": w,
+        "dominant": dominant(per), "kernels": {k_: {"share": v["share"], "avg_us": v["avg_us"], "alg_gbps": v["alg_gbps"]} for k_, v in per.items()},
+        "check_max_abs_vs_cpu_oracle": (out[:k].cpu() - ref).abs().max().item(),
+        "check": f"first {k} images, all {n} steps, fp32 CPU oracle (bf16 tolerance: per-step eps 2e-2)"}
+    del mb, out
+
+    # ---- cfg5: widened UNet 64x64x3, C=256, attention at 16x16 on / off, fp32 (configs[4]; attention build-defined)
+    B, n = 256, 50
+    for attn in (False, True):
+        d.set_seed(7)
+        mw = d.UNetMini(image_size=64, in_channels=3, out_channels=3, model_channels=256, attention=attn).eval()
+        sdw = {k_: v.detach().cpu() for k_, v in mw.state_dict().items()}
+        x_T = torch.randn((B, 3, 64, 64), generator=torch.Generator().manual_seed(14))
+        xd = x_T.to(dev)
+        dt, out = timed_passes(lambda: smp.sample_from(mw, xd), 1)
+        per, _ = profile_model(mw, sched, B, 64, 64, reps=2)
+        fl = flop_per_image_step(256, 4096, 3, 3)
+        with torch.no_grad():
+            ref = O.unet_forward(sdw, x_T[-2:], torch.tensor(500))
+        got = mw(xd[-2:].contiguous(), torch.tensor(500)).cpu()
+        res["cfg5_wide64x64x3_c256" + ("_attention" if attn else "")] = {
+            "images_per_s": B / dt, "ms_per_pass": 1e3 * dt, "batch": B, "steps": n,
+            "frac_fp32_mfma_peak_whole_path_algorithmic": B / dt * n * fl / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "dominant": dominant(per),
+            "attention": ({"share": per["attention"]["share"], "avg_us": per["attention"]["avg_us"], "tflops": per["attention"]["tflops"],
+                           "executed_mfma_frac": per["attention"]["executed_mfma_frac"]} if attn else None),
+            "check_max_abs_vs_cpu_oracle": (got - ref).abs().max().item(), "check": "one denoiser evaluation (t=500) of the last 2 images"}
+        del mw, out, xd
+        torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -40,6 +216,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per pass")
+    ap.add_argument("--total-images", type=int, default=0,
+                    help="strong scaling: the whole job is this many images per pass, T/N per GPU (BASELINE configs[2]: 65536)")
     ap.add_argument("--ddim-steps", type=int, default=50, help="number of sampler steps (both samplers)")
     ap.add_argument("--sampler", default="ddim", choices=["ddim", "ancestral"],
                     help="ancestral with --ddim-steps 1000 --batch 64 --eta 1 = BASELINE configs[0] (not the default metric)")
@@ -47,8 +225,11 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = BASELINE configs[3] arithmetic (not the default metric)")
     ap.add_argument("--cfg", action="store_true", help="class-conditional + classifier-free guidance (doubled batch)")
+    ap.add_argument("--model", default="mnist", choices=["mnist", "wide", "wide-attn"],
+                    help="wide = BASELINE configs[4]: 64x64x3, C=256 (use --batch 256); wide-attn adds the build-defined attention blocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the bounded runs of the other BASELINE configurations")
     args = ap.parse_args()
 
     if os.environ.get("DM_BENCH_WATCHDOG"):  # rehearsal aid: dump every thread's stack and exit after N seconds
@@ -88,20 +269,28 @@ def main():
     import diffusion_model_amd as d
     from diffusion_model_amd import _lib
 
-    B, n = args.batch, args.ddim_steps
+    strong = args.total_images > 0
+    if strong and args.total_images % world:
+        raise SystemExit(f"--total-images {args.total_images} is not divisible by {world} GPUs")
+    B, n = (args.total_images // world if strong else args.batch), args.ddim_steps
     d.set_seed(42)
-    model = d.UNetMini(image_size=32, precision=args.precision).eval()  # random-init weights, reference architecture
+    IMG, CIN, CH = (32, 1, 64) if args.model == "mnist" else (64, 3, 256)
+    flop_img_step = FLOP_PER_IMAGE_STEP if args.model == "mnist" else flop_per_image_step(CH, IMG * IMG, CIN, CIN)
+    model = d.UNetMini(image_size=IMG, in_channels=CIN, out_channels=CIN, model_channels=CH, precision=args.precision,
+                       attention=args.model == "wide-attn").eval()  # random-init weights, reference architecture
     sched = d.DDPMScheduler()
     eta = args.eta if args.eta is not None else (0.0 if args.sampler == "ddim" else 1.0)
     smp = d.create_sampler(args.sampler, sched, num_inference_steps=n, eta=eta)
     # synthetic x_T: the full [world*B] draw, each rank takes its row slice
     from diffusion_model_amd.distributed import sample_sharded, sampler_fn
     g = torch.Generator().manual_seed(42)
-    x_T_full = torch.randn((world * B, 1, 32, 32), generator=g).to(dev)  # same draw on every rank
+    x_T_host = torch.randn((world * B, CIN, IMG, IMG), generator=g)  # same draw on every rank
+    x_T_full = x_T_host.to(dev)
     x_T = x_T_full[rank * B:(rank + 1) * B]
     fn = sampler_fn(smp, model)
+    nz_local = None
     if eta > 0:  # per-step noise of this rank's rows, resident in HBM like x_T
-        nz_local = torch.randn((n, B, 1, 32, 32), generator=torch.Generator().manual_seed(43 + rank)).to(dev)
+        nz_local = torch.randn((n, B, CIN, IMG, IMG), generator=torch.Generator().manual_seed(43 + rank)).to(dev)
         fn = lambda x, nz: smp.sample_from(model, x, nz_local)
     if args.cfg:  # build-defined guided sampling: labels arange % 10, null class 10, w = 3
         cc = d.ClassConditioner(11, 128)
@@ -142,71 +331,68 @@ def main():
     out = out[rank * B:(rank + 1) * B]
     images = world * B * args.steps
     value = images / dt
+    default_cfg = (args.sampler, n, eta, B, args.precision, args.cfg, args.model) == ("ddim", 50, 0.0, 1024, "fp32", False, "mnist")
     res = {
-        "metric": f"sampled images/sec ({'DDIM' if args.sampler == 'ddim' else 'DDPM-ancestral'}-{n}, 32x32 MNIST UNet)", "value": value, "unit": "images/s",
+        "metric": f"sampled images/sec ({'DDIM' if args.sampler == 'ddim' else 'DDPM-ancestral'}-{n}, {IMG}x{IMG} {'MNIST' if args.model == 'mnist' else 'widened'} UNet)", "value": value, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.sampler.upper()}-{n} eta={eta:g}, UNetMini(32x32, C=64) random-init seed 42, batch {B} per GPU, "
+        "config": {"workload": f"{args.sampler.upper()}-{n} eta={eta:g}, UNetMini({IMG}x{IMG}x{CIN}, C={CH}{', attention' if args.model == 'wide-attn' else ''}) random-init seed 42, batch {B} per GPU, "
                                "x_T resident in HBM"
-                               + (" (BASELINE configs[1])" if (args.sampler, n, eta, B) == ("ddim", 50, 0.0, 1024) else ""),
+                               + (" (BASELINE configs[1])" if default_cfg and not strong else "")
+                               + (f" (BASELINE configs[2]: {args.total_images} images sharded over {world} GPUs)" if strong else ""),
                    "images_per_gpu": B, "ddim_steps": n, "guidance": bool(args.cfg), "parallelism": f"dp{world} (batch-sharded, final all-gather)"},
-        "achieved_tflops_whole_path": value * n * FLOP_PER_IMAGE_STEP / 1e12,
-        "frac_fp32_mfma_peak_whole_path": value * n * FLOP_PER_IMAGE_STEP / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
+        "achieved_tflops_whole_path": value * n * flop_img_step / 1e12,
+        "frac_fp32_mfma_peak_whole_path": value * n * flop_img_step / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
     }
 
+    if rank == 0 and world == 1:
+        # end to end: x_T uploaded from (pinned) host memory and the finished samples downloaded inside the timed region
+        xh = x_T_host.pin_memory()
+        oh = torch.empty_like(xh).pin_memory()
+
+        def e2e_pass():
+            o = fn(xh.to(dev, non_blocking=True), None)
+            oh.copy_(o, non_blocking=True)
+            return o
+        dte, _ = timed_passes(e2e_pass, max(2, args.steps), warm=1)
+        res["end_to_end"] = {"value": B / dte, "unit": "images/s", "ms_per_step": 1e3 * dte,
+                             "includes": "x_T H2D (pinned host, 4 KiB/image) + sampling + D2H of the samples; `value` above is the HBM-resident rate"}
+
     if rank == 0 and not args.no_roofline:  # (any N: rank 0's own kernels; the other ranks wait at the final barrier)
-        L = _lib.lib()
-        ws = model.workspace(B, 32, 32)
-        packed = model.packed_weights()
-        t_dev = torch.tensor([500], device=dev)
-        coef = sched.step_coefs(torch.tensor([500]), 0.0)[0]
-        cbuf = (C.c_float * 5)(*[float(v) for v in coef[:5]])
-        counts, ms = (C.c_int * NK)(), (C.c_float * NK)()
-        fl, by = (C.c_double * NK)(), (C.c_double * NK)()
-        xs = x_T.clone()
-        side = torch.cuda.Stream()
-        torch.cuda.synchronize()
-        for reps in (2, 10):  # first call warms up
-            _lib.check(L.dm_unet_profile(model._native(), _lib.ptr(packed), _lib.ptr(xs), _lib.ptr(t_dev), cbuf, B, 32, 32,
-                                         _lib.ptr(ws), ws.numel(), reps, side.cuda_stream, counts, ms, fl, by))
-        per = {}
-        tot_ms = sum(ms[k] for k in range(NK))
-        for k in range(NK):
-            if counts[k]:
-                per[K_NAMES[k]] = {"launches": counts[k], "avg_us": 1e3 * ms[k] / counts[k], "share": ms[k] / tot_ms,
-                                   "tflops": fl[k] / (ms[k] * 1e-3) / 1e12, "alg_gbps": by[k] / (ms[k] * 1e-3) / 1e9}
-        k = 1 if args.precision == "bf16" else 10  # dominant: conv_bf16_kernel<2,0> / conv_mfma_kernel<2,5,64> (DM_K_WINO)
+        per, raw = profile_model(model, sched, B, IMG, IMG, reps=10 if args.model == "mnist" else 3)
+        counts, ms, fl, by, tot_ms = raw["counts"], raw["ms"], raw["fl"], raw["by"], raw["tot_ms"]
+        k = 1 if args.precision == "bf16" else K_WINO  # dominant: conv_bf16_kernel<2,0> / conv_mfma_kernel<2,5,64> (DM_K_WINO)
         ach = fl[k] / (ms[k] * 1e-3) / 1e12
         traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic_wino.json")
-        if os.path.exists(tpath) and B == 1024:
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+        if os.path.exists(TRAFFIC_FILE) and B == 1024 and args.precision == "fp32":
+            traffic = json.load(open(TRAFFIC_FILE)).get("hbm_bytes_per_launch")
         if args.precision == "bf16":
             # at 16x the MFMA rate the bf16 conv kernel is bound by its activation traffic
             gbps = by[k] / (ms[k] * 1e-3) / 1e9
             res["roofline"] = {"kernel": "conv_bf16_kernel<2,0> (3x3 implicit GEMM, v_mfma_f32_32x32x16_bf16)",
-                               "bound": "hbm", "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+                               "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                                "traffic": None, "avg_launch_us": 1e3 * ms[k] / counts[k],
                                "algorithmic_bytes_per_launch": by[k] / counts[k], "share_of_denoiser_time": ms[k] / tot_ms}
         else:
-          res["roofline"] = {"kernel": "conv_mfma_kernel<2,5,64> (3x3 conv as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32; "
-                                       "achieved = ALGORITHMIC direct-conv FLOPs / time, the kernel executes 4/9 of them)",
-                             "executed_mfma_frac": ach * (4.0 / 9.0) / PEAK_FP32_MFMA_TFLOPS,
-                             "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                             "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, B=1024)",
-                             "algorithmic_bytes_per_launch": by[k] / counts[k],
-                             "avg_launch_us": 1e3 * ms[k] / counts[k], "flop_per_launch": fl[k] / counts[k],
-                             "share_of_denoiser_time": ms[k] / tot_ms}
+            exe = ach * (4.0 / 9.0)
+            res["roofline"] = {"kernel": "conv_mfma_kernel<2,5,64> (3x3 conv as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
+                               "bound": "mfma", "achieved": exe, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": exe / PEAK_FP32_MFMA_TFLOPS,
+                               "note": "achieved/frac = EXECUTED MFMA FLOPs (the Winograd form executes 4/9 of the direct-conv FLOPs); "
+                                       "algorithmic_* price the direct-conv FLOPs of SURVEY 8(d) and may exceed the peak",
+                               "algorithmic_achieved": ach, "algorithmic_frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                               "traffic": traffic,
+                               "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, B=1024)",
+                               "algorithmic_bytes_per_launch": by[k] / counts[k],
+                               "avg_launch_us": 1e3 * ms[k] / counts[k], "flop_per_launch": fl[k] / counts[k],
+                               "share_of_denoiser_time": ms[k] / tot_ms}
         res["kernels"] = per
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.cfg:
         from oracle import unet_oracle as O
         sd = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
-        cb = 512  # ~10 s of CPU work on the 16 host cores of the GPU box
-        xc = x_T[:cb].cpu()
-        cb = min(cb, B)
+        cb = min(512 if args.model == "mnist" else 4, B)  # ~10 s of CPU work on the 16 host cores of the GPU box
         xc = x_T[:cb].cpu()
         nzc = nz_local[:, :cb].cpu() if eta > 0 else None
         O.sample(sd, O.make_schedule(), xc.shape, 2, 0.0, x_T=xc)  # warm-up
@@ -221,6 +407,14 @@ def main():
         if eta == 0 and n <= 50 and args.precision == "fp32" and not err <= 1e-3:
             # a throughput number for wrong samples is worthless: refuse to print one
             raise SystemExit(f"bench: GPU samples differ from the CPU oracle by {err:.3g} (> 1e-3) on the first {cb} images")
+
+    if rank == 0 and world == 1 and default_cfg and not strong and not args.no_configs:
+        from oracle import unet_oracle as O
+        sd32 = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
+        del out, x_T_full
+        model._ws = None
+        torch.cuda.empty_cache()
+        res["configs"] = run_configs(d, O, dev, sd32)
 
     if saved_stdout is not None:
         sys.stdout.flush()
