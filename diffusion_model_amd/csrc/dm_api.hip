@@ -162,12 +162,12 @@ int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   return 0;
 }
 
-template <int MB, int KIND>
+template <int MB, int KIND, bool INIT = false>
 int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_done[DM_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MB, KIND>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MB, KIND, INIT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
@@ -177,7 +177,7 @@ int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
   const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : 4;
   const int cin = a.C1 + a.C2;
   ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 2.0 * (ipix * cin + opix * a.Cout + taps * (KIND == 2 ? 4 : 1) * cin * a.Cout));
-  hipLaunchKernelGGL((conv_bf16_kernel<MB, KIND>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_bf16_kernel<MB, KIND, INIT>), grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -260,7 +260,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   const int groups = (c.B + g.ni - 1) / g.ni;
   dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), (c.kind == 2 && !fused_up) ? 4u : 1u);
   a.ntiles = (int)grid.x;
-  if (!c.bf16) {  // persistent fp32 kernel: at most 3 (Winograd: 2) resident workgroups per CU (256 CUs)
+  {  // persistent kernels: at most 3 (Winograd: 2) resident workgroups per CU
     const unsigned slots = (c.kind == 5 ? 2u : 3u) * cu_count(current_device());  // (measured: 2 vs 3 per CU for the direct kernels is a wash)
     const unsigned resident = slots / (grid.y * grid.z) ? slots / (grid.y * grid.z) : 1u;
     if (grid.x > resident) grid.x = resident;
@@ -269,6 +269,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
     a.xcd_map = (grid.x % 8 == 0 && grid.y == 1 && grid.z == 1 && groups >= 64) ? 1 : 0;
   }
   if (c.bf16) {
+    if (c.kind == 0 && c.init_x) return g.MT == 128 ? launch_conv_bf16_t<2, 0, true>(a, grid, lds, s) : launch_conv_bf16_t<1, 0, true>(a, grid, lds, s);
     if (c.kind == 0) return g.MT == 128 ? launch_conv_bf16_t<2, 0>(a, grid, lds, s) : launch_conv_bf16_t<1, 0>(a, grid, lds, s);
     if (c.kind == 2) return g.MT == 128 ? launch_conv_bf16_t<2, 2>(a, grid, lds, s) : launch_conv_bf16_t<1, 2>(a, grid, lds, s);
     return launch_conv_bf16_t<1, 1>(a, grid, lds, s);

@@ -227,6 +227,13 @@ __device__ __forceinline__ void stage_init_tile(const ConvArgs& p, void* tile_v,
 
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // RNE (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((unsigned)b << 16); }
+// IEEE half, used by the bf16 path for tensors whose consumer normalises them (GroupNorm subtracts the group mean:
+// bf16's 8-bit mantissa on the RAW conv output is amplified by |mean|/sigma; half keeps 11 bits at the same 2 bytes).
+// Clamped to the finite half range so an outlier saturates instead of turning into inf -> NaN after normalisation.
+__device__ __forceinline__ bf16_t f2h(float f) {
+  return __builtin_bit_cast(bf16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
+}
+__device__ __forceinline__ float h2f(bf16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
 
 template <int MB, int KIND, bool BF = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[MB], float* scratch, float* otile,
@@ -255,7 +262,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = wm * (32 * MB) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (BF) reinterpret_cast<bf16_t*>(otile)[m * 72 + lc] = f2bf(acc[mb][r]);  // [MT][64+8] bf16
+        // [MT][64+8] 16-bit: half when the consumer normalises this tensor (it asked for statistics), else bf16
+        if (BF) reinterpret_cast<bf16_t*>(otile)[m * 72 + lc] = p.stats_out ? f2h(acc[mb][r]) : f2bf(acc[mb][r]);
         else otile[m * ORS + lc] = acc[mb][r];
       }
   } else {
@@ -303,7 +311,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
         if (n < p.B) {
           auto at = [&](int r, int c) {
             const int m = (i << rows_log) + r;
-            return BF ? bf2f(reinterpret_cast<const bf16_t*>(otile)[m * 72 + g * G + c]) : otile[m * ORS + g * G + c];
+            return BF ? h2f(reinterpret_cast<const bf16_t*>(otile)[m * 72 + g * G + c]) : otile[m * ORS + g * G + c];
           };
           float sm = 0.f;
           for (int r = 0; r < rows_img; ++r)

@@ -1,5 +1,7 @@
 // dm_kernels_bf16.hip — bf16 variant of the conv kernel (BASELINE configs[3]: bf16 activations
-// and weights, fp32 accumulate and fp32 GroupNorm statistics/transform).  Same structure as
+// and weights, fp32 accumulate and fp32 GroupNorm statistics/transform).  16-bit storage between
+// kernels: bf16 for tensors that feed an MFMA as they are, IEEE half for the raw conv outputs a
+// consumer normalises first (see f2h in dm_kernels.hip); the MFMA operands are always bf16.  Same structure as
 // conv_mfma_kernel (dm_kernels.hip) on v_mfma_f32_32x32x16_bf16, which is 16x the fp32 MFMA
 // rate: the kernel is then bound by staging (HBM + the SiLU transform) and the epilogue, so
 // activations are stored as bf16 NHWC (128 B per pixel at C = 64) to halve the HBM traffic.
@@ -11,8 +13,23 @@
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-template <int MB, int KIND>
-__global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const ConvArgs p) {
+// Weights are a PAIR of bf16 values per element, w = hi + lo (lo = bf16(w - hi), packed behind the hi
+// block): two MFMAs per A fragment, no extra vector work.  bf16 weights alone cost ~0.9e-2 of the 2e-2
+// per-step eps budget (as much as the bf16 activations); the pair removes that share at the price of MFMA
+// slots, which this kernel has to spare (it is bound by staging latency and the SiLU transform's VALU).
+//
+// Workgroups are persistent (<= 3 per CU, XCD-aware tile order as conv_mfma_kernel).  Measured and NOT
+// adopted: issuing the next tile's loads before the current K loop (two workgroups per CU for the registers it
+// takes: 309 -> 326 us per 3x3 launch at B = 2048).  With three waves per SIMD the kernel is bound by instruction
+// issue (SiLU transform + MFMA), not by load latency.
+#ifndef DM_BF16_WG
+#define DM_BF16_WG 3
+#endif
+#ifndef DM_BF16_SPLITW
+#define DM_BF16_SPLITW 1
+#endif
+template <int MB, int KIND, bool INIT = false>  // INIT: down1.conv1 with init_conv folded into its staging
+__global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvArgs p) {
   constexpr int KC = 64;
   constexpr int MT = 64 * MB;
   constexpr int RSB = KC + 8;  // LDS row stride in bf16 (144 B: 16-B skew between pixels)
@@ -20,6 +37,8 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const ConvArgs p) {
   constexpr int NTY = (KIND == 0) ? 3 : (KIND == 1) ? 4 : 2;
   constexpr int NT = NTY * NTY;
   constexpr int NJ = KC / 16;
+  constexpr int V = KC / 8;  // 16-byte loads per pixel and chunk
+  constexpr int U = 6;       // loads per thread and staging batch (one batch covers a 10x18 halo tile)
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   __builtin_amdgcn_s_setprio(2);
@@ -29,21 +48,15 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const ConvArgs p) {
   const int par = (KIND == 2) ? blockIdx.z : 0;
   const int py = par >> 1, px = par & 1;
   const int th = 1 << p.th_log, tw = 1 << p.tw_log;
-  const int t = blockIdx.x;
-  const int img0 = (t / p.tiles_per_img) * p.ni;
-  const int tin = t % p.tiles_per_img;
-  const int y0 = (tin / p.tiles_x) << p.th_log;
-  const int x0 = (tin % p.tiles_x) << p.tw_log;
-  const int hy0 = (KIND == 0) ? y0 - 1 : (KIND == 1) ? 2 * y0 - 1 : y0 - 1 + py;
-  const int hx0 = (KIND == 0) ? x0 - 1 : (KIND == 1) ? 2 * x0 - 1 : x0 - 1 + px;
   const int hth = p.hth, htw = p.htw;
   const int NP = p.ni * hth * htw;
+  const int items = NP * V;
+  const int step_now = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
 
   const bool tf = p.stats_in != nullptr;
-  float* s_mean = smem;
-  float* s_scale = s_mean + (tf ? p.ni * p.C1 : 0);
-  float* s_beta = s_scale + (tf ? p.ni * p.C1 : 0);
-  float* s_temb = s_beta + (tf ? p.C1 : 0);
+  float* s_scale = smem;
+  float* s_shift = s_scale + (tf ? p.ni * p.C1 : 0);
+  float* s_temb = s_shift + (tf ? p.ni * p.C1 : 0);
   bf16_t* tile = reinterpret_cast<bf16_t*>(s_temb + (tf ? p.ni * p.C1 : 0));
 
   int abase[MB];  // bf16 offsets
@@ -60,163 +73,199 @@ __global__ __launch_bounds__(256, 3) void conv_bf16_kernel(const ConvArgs p) {
   const int nb32 = p.Cout >> 5;
   const size_t jstride = (size_t)nb32 * 512;               // bf16 elements per (16 ch, all couts)
   const size_t tapstride = (size_t)(Cin >> 4) * jstride;
+  const size_t lo_off = (size_t)((KIND == 2) ? 4 * NT : NT) * tapstride;  // the lo halves follow all hi halves
   const int nchunks = Cin / KC;
-  constexpr int V = KC / 8;
-  constexpr int U = 6;
-  const int items = NP * V;
   const bf16_t* wpk = reinterpret_cast<const bf16_t*>(p.wp);
 
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  // tile index -> (first image, tile inside the image, output origin, halo origin)
+  struct TileAt { int img0, tin, y0, x0, hy0, hx0; };
+  auto tile_at = [&](int t) {
+    TileAt a;
+    a.img0 = (t >> p.tpi_log) * p.ni;
+    a.tin = t & (p.tiles_per_img - 1);
+    a.y0 = (a.tin >> p.tx_log) << p.th_log;
+    a.x0 = (a.tin & (p.tiles_x - 1)) << p.tw_log;
+    a.hy0 = (KIND == 0) ? a.y0 - 1 : (KIND == 1) ? 2 * a.y0 - 1 : a.y0 - 1 + py;
+    a.hx0 = (KIND == 0) ? a.x0 - 1 : (KIND == 1) ? 2 * a.x0 - 1 : a.x0 - 1 + px;
+    return a;
+  };
+  // Halo coordinates of this thread's first-batch loads do not depend on the tile: (image << 16 | hy << 8 | hx),
+  // computed once per workgroup (two multiply-high divisions per load otherwise, at a quarter of the vector rate).
+  int hyx0[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int pix = (u * 256 + tid) >> 3;
+    const int r = __umulhi((unsigned)pix, p.mg_htw);
+    const int i = __umulhi((unsigned)r, p.mg_hth);
+    hyx0[u] = (i << 16) | ((r - i * hth) << 8) | (pix - r * htw);
+  }
+  // Issue one batch of staging loads (unconditional, from clamped addresses; padding is decided by `inbm`).
+  auto issue = [&](const TileAt& a, int chunk, int base, uint4 (&v)[U], unsigned& inbm) {
     const int cg0 = chunk * KC;
     const bool from2 = cg0 >= p.C1;
     const bf16_t* src = reinterpret_cast<const bf16_t*>(from2 ? p.x2 : p.x1);
-    const int Cs = from2 ? p.C2 : p.C1;
+    const int cs_log = from2 ? p.c2_log : p.c1_log;
     const int coff = from2 ? cg0 - p.C1 : cg0;
-    const bf16_t* wbase = wpk + ((size_t)par * NT) * tapstride + (size_t)chunk * NJ * jstride +
-                          (size_t)(blockIdx.y * 2 + wn) * 512 + lane * 8;
-    if (chunk > 0) {
-      __builtin_amdgcn_s_setprio(2);
-      __syncthreads();
-    }
-    if (KIND == 0 && p.init_x) {
-      stage_init_tile<true, RSB>(p, tile, reinterpret_cast<float*>(tile + ((NP * RSB + 7) & ~7)), cg0, img0, hy0, hx0, hth, htw, tid);
-    } else
-    for (int base = 0; base < items; base += 256 * U) {
-      uint4 v[U];
-      int meta[U];
+    const int imax = p.B - 1 - a.img0;
+    int tq = threadIdx.x;  // opaque copy: the index math below is redone per call, not hoisted and kept live (spilled)
+    asm volatile("" : "+v"(tq));
+    // 64-bit base of this tile's first image + 32-bit offsets inside the tile's image group
+    const bf16_t* srcb = src + ((size_t)a.img0 << (p.h_log + p.w_log + cs_log)) + coff;
+    inbm = 0;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = base + u * 256 + tid;
-        const int pix = idx / V, c8 = idx - pix * V;
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * 256 + tq;
+      const int c8 = idx & 7;
+      int hx, hy, i;
+      if (base == 0) {
+        hx = hyx0[u] & 255; hy = (hyx0[u] >> 8) & 255; i = hyx0[u] >> 16;
+      } else {
+        const int pix = idx >> 3;
         const int r = __umulhi((unsigned)pix, p.mg_htw);
-        const int hx = pix - r * htw;
-        const int i = __umulhi((unsigned)r, p.mg_hth);
-        const int hy = r - i * hth;
-        const int iy = hy0 + hy, ix = hx0 + hx, n = img0 + i;
-        meta[u] = (idx < items) ? pix * RSB + c8 * 8 : -1;
-        const bool inb = idx < items && n < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const int cn = min(n, p.B - 1), cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-        const int cc = (idx < items) ? c8 * 8 : 0;
-        v[u] = *reinterpret_cast<const uint4*>(src + (((size_t)cn * p.H + cy) * p.W + cx) * Cs + coff + cc);
-        if (inb) meta[u] |= (i * p.C1 + coff + c8 * 8 + 1) << 16;
+        hx = pix - r * htw;
+        i = __umulhi((unsigned)r, p.mg_hth);
+        hy = r - i * hth;
       }
-      if (tf && chunk == 0 && base == 0) {
-        const int G = p.C1 / DM_GROUPS;
-        const int step = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
-        const float* te = p.temb ? p.temb + (size_t)step * p.temb_step_stride : nullptr;
-        for (int idx = tid; idx < p.ni * p.C1; idx += 256) {
-          const int i = idx / p.C1, c = idx - i * p.C1;
-          const int n = img0 + i;
-          float mean = 0.f, scale = 0.f, tv = 0.f;
-          if (n < p.B) {
-            const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c / G)) * 2;
-            float msum = 0.f, m2 = 0.f, dev = 0.f;
-            if (p.pin <= 8) {  // all partials in one round of independent loads (same arithmetic)
-              float2 pr[8];
+      const int iy = a.hy0 + hy, ix = a.hx0 + hx;
+      const bool inb = idx < items && i <= imax && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const int cn = min(i, imax), cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+      const unsigned off = ((unsigned)(((cn << p.h_log) + cy) << p.w_log) + cx) << cs_log;
+      v[u] = *reinterpret_cast<const uint4*>(srcb + off + c8 * 8);
+      inbm |= inb ? (1u << u) : 0u;
+    }
+  };
+  // Transform (GroupNorm + SiLU + time embedding, fp32) and store one batch into the LDS tile as bf16.
+  auto consume = [&](int chunk, int base, uint4 (&v)[U], unsigned inbm) {
+    const int cg0 = chunk * KC;
+    const int coff = (cg0 >= p.C1) ? cg0 - p.C1 : cg0;
+    int tq = threadIdx.x;
+    asm volatile("" : "+v"(tq));
 #pragma unroll
-              for (int q = 0; q < 8; ++q) pr[q] = *reinterpret_cast<const float2*>(st + (q < p.pin ? q : 0) * DM_GROUPS * 2);
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * 256 + tq;
+      if (idx < items) {
+        const int pix = idx >> 3, c8 = idx & 7;
+        uint4 w = v[u];
+        if (!((inbm >> u) & 1)) {
+          w = make_uint4(0u, 0u, 0u, 0u);  // zero padding / images past the batch stay exactly 0
+        } else if (tf) {
+          const int i = (p.ni == 1) ? 0 : (base == 0) ? (hyx0[u] >> 16) : (int)__umulhi(__umulhi((unsigned)pix, p.mg_htw), p.mg_hth);
+          const int tofs = (i << p.c1_log) + coff + c8 * 8;
+          unsigned wi[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-              for (int q = 0; q < 8; ++q) if (q < p.pin) msum += pr[q].x;
-              mean = msum / (float)p.pin;
-#pragma unroll
-              for (int q = 0; q < 8; ++q) if (q < p.pin) {
-                const float d = pr[q].x - mean;
-                m2 += pr[q].y;
-                dev += d * d;
-              }
+          for (int q = 0; q < 4; q += 2) {  // four elements per round: one 16-byte read of each table
+            const float4 sc = *reinterpret_cast<const float4*>(s_scale + tofs + 2 * q);
+            const float4 sh = *reinterpret_cast<const float4*>(s_shift + tofs + 2 * q);
+            const float4 te = *reinterpret_cast<const float4*>(s_temb + tofs + 2 * q);
+            // normalised inputs are stored as half (see f2h)
+            float e0 = fmaf(h2f((bf16_t)(wi[q] & 0xffffu)), sc.x, sh.x), e1 = fmaf(h2f((bf16_t)(wi[q] >> 16)), sc.y, sh.y);
+            float e2 = fmaf(h2f((bf16_t)(wi[q + 1] & 0xffffu)), sc.z, sh.z), e3 = fmaf(h2f((bf16_t)(wi[q + 1] >> 16)), sc.w, sh.w);
+            if (p.tf_silu) {
+              e0 = dm_silu_add(e0, te.x); e1 = dm_silu_add(e1, te.y); e2 = dm_silu_add(e2, te.z); e3 = dm_silu_add(e3, te.w);
             } else {
-              for (int q = 0; q < p.pin; ++q) msum += st[q * DM_GROUPS * 2];
-              mean = msum / (float)p.pin;
-              for (int q = 0; q < p.pin; ++q) {
-                const float d = st[q * DM_GROUPS * 2] - mean;
-                m2 += st[q * DM_GROUPS * 2 + 1];
-                dev += d * d;
-              }
+              e0 += te.x; e1 += te.y; e2 += te.z; e3 += te.w;
             }
-            const float var = (m2 + p.cnt_in * dev) / (p.cnt_in * (float)p.pin);
-            scale = rsqrtf(var + DM_GN_EPS) * p.gamma[c];
-            if (te) tv = te[(size_t)n * p.temb_stride + c];
+            wi[q] = (unsigned)f2bf(e0) | ((unsigned)f2bf(e1) << 16);
+            wi[q + 1] = (unsigned)f2bf(e2) | ((unsigned)f2bf(e3) << 16);
           }
-          s_mean[idx] = mean;
-          s_scale[idx] = scale;
-          s_temb[idx] = tv;
+          w = make_uint4(wi[0], wi[1], wi[2], wi[3]);
         }
-        for (int c = tid; c < p.C1; c += 256) s_beta[c] = p.beta[c];
-        __syncthreads();
+        *reinterpret_cast<uint4*>(tile + pix * RSB + c8 * 8) = w;
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (meta[u] >= 0) {
-          uint4 w = v[u];
-          const int lofs = meta[u] & 0xffff, tofs = (meta[u] >> 16) - 1;
-          if (tofs < 0) w = make_uint4(0u, 0u, 0u, 0u);
-          if (tf && tofs >= 0) {
-            const int c = coff + (lofs % RSB);
-            unsigned wi[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float lo = __uint_as_float(wi[q] << 16), hi = __uint_as_float(wi[q] & 0xffff0000u);
-              const int e = 2 * q;
-              lo = (lo - s_mean[tofs + e]) * s_scale[tofs + e] + s_beta[c + e];
-              hi = (hi - s_mean[tofs + e + 1]) * s_scale[tofs + e + 1] + s_beta[c + e + 1];
-              if (p.tf_silu) { lo = dm_silu(lo); hi = dm_silu(hi); }
-              lo += s_temb[tofs + e];
-              hi += s_temb[tofs + e + 1];
-              wi[q] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-            }
-            w = make_uint4(wi[0], wi[1], wi[2], wi[3]);
+      __builtin_amdgcn_sched_barrier(0);  // one load's chain at a time: the other two waves of the SIMD fill the gaps,
+    }                                     // and six interleaved chains do not fit 168 registers
+  };
+
+  // persistent tile walk (see conv_mfma_kernel for the XCD-aware order)
+  const int t_first = p.xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t_step = p.xcd_map ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int t_xcd = p.xcd_map ? (int)(blockIdx.x & 7) : 0;
+  const int t_end = p.xcd_map ? (((p.ngroups - t_xcd + 7) >> 3) << p.tpi_log) : p.ntiles;
+  auto tile_of = [&](int ts) {
+    return p.xcd_map ? (((((ts >> p.tpi_log) << 3) + t_xcd) << p.tpi_log) | (ts & (p.tiles_per_img - 1))) : ts;
+  };
+  for (int ts = t_first; ts < t_end; ts += t_step) {
+    const TileAt at = tile_at(tile_of(ts));
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const bf16_t* wbase = wpk + ((size_t)par * NT) * tapstride + (size_t)chunk * NJ * jstride +
+                            (size_t)(blockIdx.y * 2 + wn) * 512 + lane * 8;
+      if (chunk > 0) {
+        __builtin_amdgcn_s_setprio(2);
+        __syncthreads();  // previous chunk's LDS reads are done
+      }
+      if constexpr (INIT) {
+        stage_init_tile<true, RSB>(p, tile, reinterpret_cast<float*>(tile + ((NP * RSB + 7) & ~7)), chunk * KC, at.img0, at.hy0, at.hx0, hth, htw, tid);
+      } else {
+        for (int base = 0; base < items; base += 256 * U) {  // uniform trip count (barrier inside)
+          uint4 v[U];
+          unsigned inbm;
+          issue(at, chunk, base, v, inbm);
+          if (tf && chunk == 0 && base == 0) {
+            gn_tables(p, step_now, at.img0, tid, s_scale, s_shift, s_temb);  // while the tile loads are in flight
+            __syncthreads();
           }
-          *reinterpret_cast<uint4*>(tile + lofs) = w;
+          consume(chunk, base, v, inbm);
         }
       }
-    }
-    uint4 bq[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) bq[j] = *reinterpret_cast<const uint4*>(wbase + j * jstride);
-    __syncthreads();
-    __builtin_amdgcn_s_setprio(0);
-    if (chunk == 0) {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-    }
-    uint4 a0[MB], a1[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) a0[mb] = *reinterpret_cast<const uint4*>(tile + abase[mb]);
-    int ty = 0, tx = 0;
-    for (int tap = 0; tap < NT; ++tap) {
-      const int tapoff = (ty * htw + tx) * RSB;
-      int ntx = tx + 1, nty = ty;
-      if (ntx == NTY) { ntx = 0; ++nty; }
-      const bool last = tap + 1 == NT;
-      const int ntapoff = last ? tapoff : (nty * htw + ntx) * RSB;
-      const bf16_t* wnext = wbase + (size_t)(last ? tap : tap + 1) * tapstride;
+      uint4 bq[NJ], bl[NJ];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        uint4* acur = (j & 1) ? a1 : a0;
-        uint4* anxt = (j & 1) ? a0 : a1;
-        const int noff = (j + 1 < NJ) ? tapoff + (j + 1) * 16 : ntapoff;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) anxt[mb] = *reinterpret_cast<const uint4*>(tile + abase[mb] + noff);
-        __builtin_amdgcn_sched_barrier(0);
-        const bf16x8_t b = __builtin_bit_cast(bf16x8_t, bq[j]);
+        bq[j] = *reinterpret_cast<const uint4*>(wbase + j * jstride);
+        bl[j] = *reinterpret_cast<const uint4*>(wbase + lo_off + j * jstride);
+      }
+      __syncthreads();
+      __builtin_amdgcn_s_setprio(0);
+      if (chunk == 0) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
-          acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[mb]), b, acc[mb], 0, 0, 0);
-        bq[j] = *reinterpret_cast<const uint4*>(wnext + j * jstride);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
       }
-      tx = ntx; ty = nty;
+      uint4 a0[MB], a1[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) a0[mb] = *reinterpret_cast<const uint4*>(tile + abase[mb]);
+      int ty = 0, tx = 0;
+#pragma unroll 1
+      for (int tap = 0; tap < NT; ++tap) {
+        const int tapoff = (ty * htw + tx) * RSB;
+        int ntx = tx + 1, nty = ty;
+        if (ntx == NTY) { ntx = 0; ++nty; }
+        const bool last = tap + 1 == NT;
+        const int ntapoff = last ? tapoff : (nty * htw + ntx) * RSB;
+        const bf16_t* wnext = wbase + (size_t)(last ? tap : tap + 1) * tapstride;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          uint4* acur = (j & 1) ? a1 : a0;
+          uint4* anxt = (j & 1) ? a0 : a1;
+          const int noff = (j + 1 < NJ) ? tapoff + (j + 1) * 16 : ntapoff;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) anxt[mb] = *reinterpret_cast<const uint4*>(tile + abase[mb] + noff);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bq[j]);
+          const bf16x8_t bw = __builtin_bit_cast(bf16x8_t, bl[j]);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) {
+            const bf16x8_t av = __builtin_bit_cast(bf16x8_t, acur[mb]);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc[mb], 0, 0, 0);
+            if (DM_BF16_SPLITW) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc[mb], 0, 0, 0);
+          }
+          bq[j] = *reinterpret_cast<const uint4*>(wnext + j * jstride);
+          bl[j] = *reinterpret_cast<const uint4*>(wnext + lo_off + j * jstride);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        tx = ntx; ty = nty;
+      }
     }
+    __builtin_amdgcn_s_setprio(2);
+    __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
+    conv_epilogue<MB, KIND, true>(p, acc, smem + MT * 36, smem, par, py, px, at.img0, at.tin, at.y0, at.x0, wm, wn, lane, h, tid, wave);
+    __syncthreads();  // output staging / reduction words are free again for the next tile
   }
-  __builtin_amdgcn_s_setprio(2);
-  __syncthreads();
-  conv_epilogue<MB, KIND, true>(p, acc, smem + MT * 36, smem, par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
 }
 
-// bf16 B-fragment packing: out[par][tap][cin/16][cout/32][lane][8] =
-//   bf16( w(cout = nb*32 + (lane&31), cin = 16*c16 + 8*(lane>>5) + e, ky, kx) )
+// bf16 B-fragment packing, each weight as a (hi, lo) bf16 pair with hi + lo ~ w to 16 mantissa bits:
+//   out[par][tap][cin/16][cout/32][lane][8] = hi = bf16( w(cout = nb*32 + (lane&31), cin = 16*c16 + 8*(lane>>5) + e, ky, kx) )
+//   out[total + the same index]             = lo = bf16( w - hi )
 __global__ void pack_conv_weight_bf16_kernel(int kind, const float* __restrict__ w, int cin, int cout,
                                              bf16_t* __restrict__ out, size_t total) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -238,7 +287,10 @@ __global__ void pack_conv_weight_bf16_kernel(int kind, const float* __restrict__
   const int ci = c16 * 16 + 8 * (lane >> 5) + e;
   const size_t src = (kind == 2) ? (((size_t)ci * cout + co) * ks + ky) * ks + kx
                                  : (((size_t)co * cin + ci) * ks + ky) * ks + kx;
-  out[idx] = f2bf(w[src]);
+  const float wv = w[src];
+  const bf16_t hi = f2bf(wv);
+  out[idx] = hi;
+  out[total + idx] = f2bf(wv - bf2f(hi));
 }
 
 // init_conv with bf16 NHWC output
@@ -342,8 +394,8 @@ __global__ __launch_bounds__(256) void final_conv_bf16_kernel(const bf16_t* __re
     for (int c4 = q; c4 < V; c4 += LP) {
       const int c = c4 * 4;
       const uint2 raw = *reinterpret_cast<const uint2*>(up + c);
-      float v[4] = {__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u),
-                    __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xffff0000u)};
+      float v[4] = {h2f((bf16_t)(raw.x & 0xffffu)), h2f((bf16_t)(raw.x >> 16)),
+                    h2f((bf16_t)(raw.y & 0xffffu)), h2f((bf16_t)(raw.y >> 16))};  // u3 is stored as half (normalised here)
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = dm_silu((v[e] - s_mean[c + e]) * s_scale[c + e] + s_beta[c + e]);
 #pragma unroll

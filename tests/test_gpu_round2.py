@@ -226,3 +226,39 @@ def test_class_conditioner_empty_labels():
     cc = d.ClassConditioner(11, 128)
     out = cc(torch.empty(0, dtype=torch.int64))
     assert out.shape == (0, 128)
+
+
+# ---------------------------------------------------------------- bf16 margin
+BF16_EPS_TOL = 2e-2      # north_star: per-step eps max-abs <= 2e-2 in bf16
+BF16_EPS_MARGIN = 1.7e-2  # what this build holds itself to, so another seed / batch / checkpoint stays inside 2e-2
+#   measured (split bf16 weights + half storage of normalised tensors): 1.42e-2 / 1.55e-2 / 1.45e-2 on the three seeds;
+#   the round-1 build gave 1.95e-2 / 2.02e-2 / 1.98e-2 on the same chains, i.e. it broke the 2e-2 bound at batch 64
+
+
+@pytest.mark.parametrize("seed", [42, 7, 123])
+def test_bf16_parity_margin_three_seeds_b64_all_steps(seed):
+    """bf16 (BASELINE configs[3]) teacher-forced on the CPU oracle's own DDIM-50 chain: 3 weight/noise seeds,
+    batch 64, all 50 steps.  The round-1 build measured 1.95e-2 on one B=4 chain: 97.5 % of the budget."""
+    d.set_seed(seed)
+    m32 = d.UNetMini(image_size=32).eval()
+    sdc = cpu_sd(m32)
+    mb = d.UNetMini(image_size=32, precision="bf16").eval()
+    mb.load_state_dict(sdc)
+    B = 64
+    x_T = torch.randn((B, 1, 32, 32), generator=torch.Generator().manual_seed(seed + 1))
+    rec = []
+    ref_out = O.sample(sdc, O.make_schedule(), x_T.shape, 50, 0.0, x_T=x_T, record=rec)
+    sched = d.DDPMScheduler()
+    smp = d.DDIMSampler(sched, num_inference_steps=50, eta=0.0)
+    worst, worst32 = 0.0, 0.0
+    for i, (t, x, eps, _) in enumerate(rec):
+        e = mb(x.to(DEV), sched.timesteps[i]).cpu()
+        worst = max(worst, (e - eps).abs().max().item())
+        if i % 10 == 0:
+            worst32 = max(worst32, (m32(x.to(DEV), sched.timesteps[i]).cpu() - eps).abs().max().item())
+    out = smp.sample_from(mb, x_T).cpu()
+    psnr = O.psnr(out, ref_out, float(ref_out.max() - ref_out.min()))
+    print(f"bf16 seed {seed}: worst per-step eps err {worst:.4e} (fp32 path {worst32:.2e}), free-running PSNR min {psnr.min().item():.1f} dB")
+    assert worst32 <= EPS_TOL
+    assert worst <= BF16_EPS_MARGIN, worst
+    assert psnr.min().item() >= 40.0
