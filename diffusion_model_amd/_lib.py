@@ -32,6 +32,7 @@ _SIGS = {
     "dm_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _sz, _i, _vp]),
     "dm_sample_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
     "dm_sampler_step_batched": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
+    "dm_attention": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "dm_final_conv": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "dm_init": (_i, []),
     "dm_noalloc_scratch_bytes": (_sz, []),

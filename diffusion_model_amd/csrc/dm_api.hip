@@ -455,6 +455,38 @@ int launch_bgemm(bool bkn, const GemmArgs& g, int batch, hipStream_t s) {
   return 0;
 }
 
+template <int NB, int CB>
+int launch_attention_t(const float* qkv, float* o, int B, int C, float scale, size_t lds, hipStream_t s) {
+  static bool attr_done[DM_MAX_DEVICES] = {false};
+  const int dev = current_device();
+  if (!attr_done[dev]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_fused_kernel<NB, CB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done[dev] = true;
+  }
+  hipLaunchKernelGGL((attention_fused_kernel<NB, CB>), dim3(NB, (unsigned)B), dim3(256), lds, s, qkv, o, C, scale);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// softmax(Q K^T / sqrt(C)) V for T in {64, 128, 256} tokens, C in {64, 128, 256, 512}: one fused kernel per
+// (image, 64-query tile), scores in LDS.  Returns -1 when the shape is outside that set (caller falls back to
+// the three-kernel form for longer sequences).
+int launch_attention_fused(const float* qkv, float* o, int B, int T, int C, hipStream_t s) {
+  const int nb = T / 64, cb = C / 64;
+  if (T % 64 || C % 64 || (nb != 1 && nb != 2 && nb != 4) || (cb != 1 && cb != 2 && cb != 4 && cb != 8)) return -1;
+  const size_t lds = ((size_t)64 * (T + 4) + 64 * 36 + (size_t)(T > C ? T : C) * 36) * sizeof(float);
+  if (lds > 160 * 1024) return -1;
+  const float scale = 1.0f / sqrtf((float)C);
+  ProfScope ps(DM_K_ATTN, s, 4.0 * B * (double)T * T * C, 4.0 * B * (double)T * 4 * C);
+#define DM_ATT(NB_, CB_) if (nb == NB_ && cb == CB_) return launch_attention_t<NB_, CB_>(qkv, o, B, C, scale, lds, s);
+  DM_ATT(1, 1) DM_ATT(1, 2) DM_ATT(1, 4) DM_ATT(1, 8)
+  DM_ATT(2, 1) DM_ATT(2, 2) DM_ATT(2, 4) DM_ATT(2, 8)
+  DM_ATT(4, 1) DM_ATT(4, 2) DM_ATT(4, 4) DM_ATT(4, 8)
+#undef DM_ATT
+  return -1;
+}
+
 // Build-defined attention block on X [B,h,w,C] in place:
 //   X += proj( softmax(Q K^T / sqrt(C)) V ),  [Q,K,V] = qkv_1x1( GroupNorm8(X) )
 // GroupNorm statistics of X come as partials from the conv that produced it.
@@ -474,6 +506,9 @@ int attention_block(const dm_unet* m, const float* P, int which, float* X, const
   c.stats_in = stats; c.pin = pin; c.cnt_in = cnt; c.gamma = P + o.ng; c.beta = P + o.nb; c.no_silu = 1;
   c.B = B; c.H = h; c.W = ww;
   if (launch_conv(c, s)) return 1;
+  const int frc = launch_attention_fused(QKV, O, B, T, C, s);
+  if (frc > 0) return 1;
+  if (frc < 0) {  // sequences beyond 256 tokens: QK^T, row softmax and PV as three kernels, scores through HBM
   GemmArgs g;
   g.A = QKV; g.Bm = QKV + C; g.C = S; g.M = T; g.N = T; g.K = C; g.lda = 3 * C; g.ldb = 3 * C; g.ldc = T;
   g.sA = (size_t)T * 3 * C; g.sB = g.sA; g.sC = (size_t)T * T; g.alpha = 1.0f / sqrtf((float)C);
@@ -487,6 +522,7 @@ int attention_block(const dm_unet* m, const float* P, int which, float* X, const
   g.A = S; g.Bm = QKV + 2 * C; g.C = O; g.M = T; g.N = C; g.K = T; g.lda = T; g.ldb = 3 * C; g.ldc = C;
   g.sA = (size_t)T * T; g.sB = (size_t)T * 3 * C; g.sC = (size_t)T * C; g.alpha = 1.0f;
   if (launch_bgemm(true, g, B, s)) return 1;
+  }
   memset(&c, 0, sizeof c);
   c.kind = 3; c.x1 = O; c.c1 = C; c.wp = P + o.proj; c.bias = P + o.projb; c.cout = C; c.y = X; c.res = X;
   c.B = B; c.H = h; c.W = ww;
@@ -844,6 +880,14 @@ int dm_sampler_step_batched(const float* x, const float* eps, const float* noise
   hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+int dm_attention(const float* qkv_dev, float* o_dev, int B, int T, int C, void* stream) {
+  if (!qkv_dev || !o_dev) return fail("dm_attention: null argument");
+  if (B <= 0) return fail("dm_attention: empty batch");
+  const int rc = launch_attention_fused(qkv_dev, o_dev, B, T, C, (hipStream_t)stream);
+  if (rc < 0) return fail("dm_attention: the fused kernel takes T in {64,128,256} tokens and C in {64,128,256,512} (got T=%d, C=%d)", T, C);
+  return rc;
 }
 
 int dm_final_conv(const float* u_dev, const float* stats_dev, int pin, float cnt_in, const float* gamma, const float* beta,

@@ -1518,6 +1518,155 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
   for (int i = lane; i < n; i += 64) r[i] *= inv;
 }
 
+// Fused single-head attention for one (image, 64-query tile): S = scale * Q K^T -> row softmax -> O = P V,
+// with the 64 x T score tile held in LDS (T <= 256 tokens: 65 KiB) - the scores never travel to HBM.
+//   qkv [B][T][3C] (q | k | v of a token, from the 1x1 qkv conv), o [B][T][C].
+// 4 waves as 2 (query rows) x 2 (columns); fp32 MFMA 32x32x2 with the conv kernels' k-permuted b128 fragment
+// reads.  NB = T/64 score blocks and CB = C/64 output blocks per wave.
+//   phase 1: K loop over C in chunks of 32 channels: Q chunk [64][36] and K chunk [T][36] staged in LDS
+//   phase 2: softmax of the 64 rows in LDS (16 rows per wave, shuffles), accurate expf
+//   phase 3: K loop over T in chunks of 32 tokens: A = P from LDS, B = V chunk staged TRANSPOSED as [C][36]
+template <int NB, int CB>
+__global__ __launch_bounds__(256) void attention_fused_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                              int C, float scale) {
+  constexpr int T = 64 * NB;
+  constexpr int PRS = T + 4;  // score row stride (floats)
+  constexpr int RS = 36;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* P = smem;                 // [64][PRS]
+  float* As = P + 64 * PRS;        // [64][RS]
+  float* Bs = As + 64 * RS;        // [max(T, C)][RS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+  const int q0 = blockIdx.x * 64;
+  const size_t ld = (size_t)3 * C;
+  const float* base = qkv + (size_t)blockIdx.y * T * ld;
+  // ---- phase 1: S = Q K^T.  Software-pipelined: the NEXT chunk's global loads are issued into registers before
+  // the MFMAs of the current chunk and written to LDS after them.
+  {
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    float4 qn[2], kn[2 * NB];
+    auto fetch = [&](int c0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {  // Q chunk: 64 rows x 8 float4
+        const int idx = tid + u * 256, row = idx >> 3, c4 = idx & 7;
+        qn[u] = *reinterpret_cast<const float4*>(base + (size_t)(q0 + row) * ld + c0 + c4 * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 2 * NB; ++u) {  // K chunk: T rows x 8 float4
+        const int idx = tid + u * 256, row = idx >> 3, c4 = idx & 7;
+        kn[u] = *reinterpret_cast<const float4*>(base + (size_t)row * ld + C + c0 + c4 * 4);
+      }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < C; c0 += 32) {
+      __syncthreads();  // the previous chunk's fragment reads are done
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = tid + u * 256, row = idx >> 3, c4 = idx & 7;
+        *reinterpret_cast<float4*>(As + row * RS + c4 * 4) = qn[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 2 * NB; ++u) {
+        const int idx = tid + u * 256, row = idx >> 3, c4 = idx & 7;
+        *reinterpret_cast<float4*>(Bs + row * RS + c4 * 4) = kn[u];
+      }
+      __syncthreads();
+      if (c0 + 32 < C) fetch(c0 + 32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 a = *reinterpret_cast<const float4*>(As + (wm * 32 + l31) * RS + j * 8 + 4 * h);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float4 b = *reinterpret_cast<const float4*>(Bs + (wn * (T / 2) + nb * 32 + l31) * RS + j * 8 + 4 * h);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nb], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        P[row * PRS + wn * (T / 2) + nb * 32 + l31] = scale * acc[nb][r];
+      }
+  }
+  __syncthreads();
+  // ---- phase 2: softmax over each of the 64 rows (16 rows per wave; a lane holds NB elements of a row)
+  for (int rr = 0; rr < 16; ++rr) {
+    float* pr = P + (wave * 16 + rr) * PRS;
+    float v[NB];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { v[k] = pr[lane + 64 * k]; mx = fmaxf(mx, v[k]); }
+    for (int o2 = 32; o2 > 0; o2 >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o2, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { v[k] = expf(v[k] - mx); sum += v[k]; }
+    for (int o2 = 32; o2 > 0; o2 >>= 1) sum += __shfl_xor(sum, o2, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) pr[lane + 64 * k] = v[k] * inv;
+  }
+  // ---- phase 3: O = P V (same pipelining)
+  {
+    f32x16 acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    float4 vn[2 * CB];
+    // V chunk [32 tokens][C]: lane -> token, 16 B per lane from global
+    auto fetch = [&](int t0) {
+#pragma unroll
+      for (int u = 0; u < 2 * CB; ++u) {
+        const int idx = tid + u * 256, k = idx & 31, quad = idx >> 5;
+        vn[u] = *reinterpret_cast<const float4*>(base + (size_t)(t0 + k) * ld + 2 * C + quad * 4);
+      }
+    };
+    fetch(0);
+    for (int t0 = 0; t0 < T; t0 += 32) {
+      __syncthreads();  // (first round: the softmax writes; later: the previous round's B reads)
+      // -> Bs[c][token] (transposed; consecutive lanes = consecutive tokens: conflict-free 4-byte LDS writes)
+#pragma unroll
+      for (int u = 0; u < 2 * CB; ++u) {
+        const int idx = tid + u * 256, k = idx & 31, quad = idx >> 5;
+        Bs[(quad * 4 + 0) * RS + k] = vn[u].x; Bs[(quad * 4 + 1) * RS + k] = vn[u].y;
+        Bs[(quad * 4 + 2) * RS + k] = vn[u].z; Bs[(quad * 4 + 3) * RS + k] = vn[u].w;
+      }
+      __syncthreads();
+      if (t0 + 32 < T) fetch(t0 + 32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 a = *reinterpret_cast<const float4*>(P + (wm * 32 + l31) * PRS + t0 + j * 8 + 4 * h);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          const float4 b = *reinterpret_cast<const float4*>(Bs + (wn * (32 * CB) + cb * 32 + l31) * RS + j * 8 + 4 * h);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[cb], 0, 0, 0);
+        }
+      }
+    }
+    float* ob = o + ((size_t)blockIdx.y * T + q0) * C;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        ob[(size_t)row * C + wn * (32 * CB) + cb * 32 + l31] = acc[cb][r];
+      }
+  }
+}
+
 // Post-processing of finished samples (diffusion/sample.py:117-119): (x + 1) / 2, clamp to [0,1];
 // optionally quantised to uint8 as torchvision.utils.save_image does (v*255 + 0.5, clamp, truncate).
 __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ x, float* __restrict__ out_f,

@@ -205,6 +205,11 @@ int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* 
  * [B][pout][8][2] partial statistics of y (pout as dm_conv_stats_partials reports).
  * H, W are the INPUT spatial dims. */
 int dm_conv_stats_partials(int kind, int H, int W);
+/* Build-defined attention core (no reference counterpart: model.py:70 "No attention layers"; BASELINE configs[4]):
+ * o[b,t,:] = softmax_s(q[b,t,:] . k[b,s,:] / sqrt(C)) v[b,s,:], single head, qkv_dev [B][T][3C] (q | k | v per token),
+ * o_dev [B][T][C].  One fused kernel per (image, 64-query tile): QK^T on fp32 MFMA into a 64 x T score tile in LDS,
+ * row softmax there, PV on fp32 MFMA; T in {64,128,256}, C in {64,128,256,512}. */
+int dm_attention(const float* qkv_dev, float* o_dev, int B, int T, int C, void* stream);
 /* final_conv (model.py:111-115,151): out[B,Cout,H,W] (NCHW) = Conv1x1(SiLU(GroupNorm8(u))), u NHWC
  * [B,H,W,C] with statistics partials as above; w [Cout,C], bias [Cout]. */
 int dm_final_conv(const float* u_dev, const float* stats_dev, int pin, float cnt_in,

@@ -262,3 +262,22 @@ def test_bf16_parity_margin_three_seeds_b64_all_steps(seed):
     assert worst32 <= EPS_TOL
     assert worst <= BF16_EPS_MARGIN, worst
     assert psnr.min().item() >= 40.0
+
+
+@pytest.mark.parametrize("B,T,C", [(3, 256, 256), (2, 64, 64), (5, 128, 64), (2, 256, 64), (2, 64, 512), (130, 64, 64)])
+def test_attention_fused_kernel(B, T, C):
+    """Build-defined attention core (parity unpinned by the reference: it has no attention): fused QK^T -> softmax -> PV
+    against torch-CPU on the same inputs."""
+    import math
+    torch.manual_seed(B + T + C)
+    L = _lib.lib()
+    qkv = torch.randn(B, T, 3 * C)
+    qkv[..., :C] *= 2.0  # sharper score rows: the max-subtraction matters
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    ref = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(C), -1) @ v
+    qd = qkv.to(DEV)
+    o = torch.full((B, T, C), float("nan"), device=DEV)
+    _lib.check(L.dm_attention(_lib.ptr(qd), _lib.ptr(o), B, T, C, torch.cuda.current_stream().cuda_stream))
+    assert (o.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    rc = L.dm_attention(_lib.ptr(qd), _lib.ptr(o), B, 96, C, torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and b"fused kernel" in L.dm_last_error()
