@@ -1,6 +1,6 @@
 # one conv layer launched a few times, for rocprofv3 --pmc passes: python3 tools/diag/pmc_layer.py [kind] [H] [B]
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from diffusion_model_amd import _lib
 L = _lib.lib()
