@@ -171,12 +171,13 @@ int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
+  constexpr bool UP = (KIND == 2 || KIND == 4);
   const int cls = KIND == 0 ? (MB == 2 ? DM_K_CONV3_128 : DM_K_CONV3_64) : KIND == 1 ? DM_K_DOWN : (MB == 2 ? DM_K_UP_128 : DM_K_UP_64);
-  const double opix = (double)a.B * a.Hb * a.Wb * (KIND == 2 ? 4 : 1);
+  const double opix = (double)a.B * a.Hb * a.Wb * (UP ? 4 : 1);
   const double ipix = (double)a.B * a.H * a.W;
   const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : 4;
   const int cin = a.C1 + a.C2;
-  ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 2.0 * (ipix * cin + opix * a.Cout + taps * (KIND == 2 ? 4 : 1) * cin * a.Cout));
+  ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 2.0 * (ipix * cin + opix * a.Cout + taps * (UP ? 4 : 1) * cin * a.Cout));
   hipLaunchKernelGGL((conv_bf16_kernel<MB, KIND, INIT>), grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -201,7 +202,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   // transposed conv with a single K chunk: all four output parities from one staged tile
   if (c.bf16 && (c.kind == 3 || c.res)) return fail("conv: the bf16 path has no 1x1 / residual variant");
   // (not below 4x4 input pixels: the tiny-image statistics path needs the staged output tile)
-  const bool fused_up = c.kind == 2 && cin == 64 && !c.bf16 && g.Hb * g.Wb >= 16;
+  const bool fused_up = c.kind == 2 && cin == 64 && g.Hb * g.Wb >= 16;
   if (fused_up) { g.hth += 1; g.htw += 1; }
   ConvArgs a;
   memset(&a, 0, sizeof a);
@@ -253,7 +254,8 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   if (c.bf16) {
     lds_f = (np * (64 + 8) + 1) / 2 + (c.stats_in ? (size_t)(3 * g.ni + 1) * c.c1 : 0) + init_f;
     const size_t e2 = (size_t)g.MT * 36 + 128;
-    if (lds_f < e2) lds_f = e2;
+    if (fused_up) lds_f += e2 + 8;  // the four parities' outputs are staged beside the input tile, not over it
+    else if (lds_f < e2) lds_f = e2;
   }
   const size_t lds = lds_f * sizeof(float);
   if (lds > 160 * 1024) return fail("conv: tile needs %zu B of LDS (> 160 KiB)", lds);
@@ -271,6 +273,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   if (c.bf16) {
     if (c.kind == 0 && c.init_x) return g.MT == 128 ? launch_conv_bf16_t<2, 0, true>(a, grid, lds, s) : launch_conv_bf16_t<1, 0, true>(a, grid, lds, s);
     if (c.kind == 0) return g.MT == 128 ? launch_conv_bf16_t<2, 0>(a, grid, lds, s) : launch_conv_bf16_t<1, 0>(a, grid, lds, s);
+    if (fused_up) return g.MT == 128 ? launch_conv_bf16_t<2, 4>(a, grid, lds, s) : launch_conv_bf16_t<1, 4>(a, grid, lds, s);
     if (c.kind == 2) return g.MT == 128 ? launch_conv_bf16_t<2, 2>(a, grid, lds, s) : launch_conv_bf16_t<1, 2>(a, grid, lds, s);
     return launch_conv_bf16_t<1, 1>(a, grid, lds, s);
   }

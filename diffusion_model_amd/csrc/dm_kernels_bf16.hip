@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
   constexpr int S = (KIND == 1) ? 2 : 1;
   constexpr int NTY = (KIND == 0) ? 3 : (KIND == 1) ? 4 : 2;
   constexpr int NT = NTY * NTY;
+  constexpr int NTOT = (KIND == 4) ? 16 : NT;  // KIND 4: the four output parities of the transposed conv from ONE staged tile
   constexpr int NJ = KC / 16;
   constexpr int V = KC / 8;  // 16-byte loads per pixel and chunk
   constexpr int U = 6;       // loads per thread and staging batch (one batch covers a 10x18 halo tile)
@@ -45,8 +46,8 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
   const int Cin = p.C1 + p.C2;
-  const int par = (KIND == 2) ? blockIdx.z : 0;
-  const int py = par >> 1, px = par & 1;
+  int par = (KIND == 2) ? blockIdx.z : 0;  // KIND 4: advances inside the K loop
+  int py = par >> 1, px = par & 1;
   const int th = 1 << p.th_log, tw = 1 << p.tw_log;
   const int hth = p.hth, htw = p.htw;
   const int NP = p.ni * hth * htw;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
   const int nb32 = p.Cout >> 5;
   const size_t jstride = (size_t)nb32 * 512;               // bf16 elements per (16 ch, all couts)
   const size_t tapstride = (size_t)(Cin >> 4) * jstride;
-  const size_t lo_off = (size_t)((KIND == 2) ? 4 * NT : NT) * tapstride;  // the lo halves follow all hi halves
+  const size_t lo_off = (size_t)((KIND == 2 || KIND == 4) ? 4 * NT : NT) * tapstride;  // the lo halves follow all hi halves
   const int nchunks = Cin / KC;
   const bf16_t* wpk = reinterpret_cast<const bf16_t*>(p.wp);
 
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
     a.tin = t & (p.tiles_per_img - 1);
     a.y0 = (a.tin >> p.tx_log) << p.th_log;
     a.x0 = (a.tin & (p.tiles_x - 1)) << p.tw_log;
-    a.hy0 = (KIND == 0) ? a.y0 - 1 : (KIND == 1) ? 2 * a.y0 - 1 : a.y0 - 1 + py;
-    a.hx0 = (KIND == 0) ? a.x0 - 1 : (KIND == 1) ? 2 * a.x0 - 1 : a.x0 - 1 + px;
+    a.hy0 = (KIND == 0 || KIND == 4) ? a.y0 - 1 : (KIND == 1) ? 2 * a.y0 - 1 : a.y0 - 1 + py;
+    a.hx0 = (KIND == 0 || KIND == 4) ? a.x0 - 1 : (KIND == 1) ? 2 * a.x0 - 1 : a.x0 - 1 + px;
     return a;
   };
   // Halo coordinates of this thread's first-batch loads do not depend on the tile: (image << 16 | hy << 8 | hx),
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
     return p.xcd_map ? (((((ts >> p.tpi_log) << 3) + t_xcd) << p.tpi_log) | (ts & (p.tiles_per_img - 1))) : ts;
   };
   for (int ts = t_first; ts < t_end; ts += t_step) {
+    if (KIND == 4) { par = 0; py = 0; px = 0; }  // (advanced by the previous tile's K loop)
     const TileAt at = tile_at(tile_of(ts));
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       const bf16_t* wbase = wpk + ((size_t)par * NT) * tapstride + (size_t)chunk * NJ * jstride +
@@ -226,12 +228,17 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
       for (int mb = 0; mb < MB; ++mb) a0[mb] = *reinterpret_cast<const uint4*>(tile + abase[mb]);
       int ty = 0, tx = 0;
 #pragma unroll 1
-      for (int tap = 0; tap < NT; ++tap) {
-        const int tapoff = (ty * htw + tx) * RSB;
+      for (int tap = 0; tap < NTOT; ++tap) {
+        // KIND 4: tap = parity*4 + (ty*2+tx); parity (py,px) reads halo rows py+ty, columns px+tx
+        const int tapoff = (KIND == 4) ? (((tap >> 3) + ((tap >> 1) & 1)) * htw + ((tap >> 2) & 1) + (tap & 1)) * RSB
+                                       : (ty * htw + tx) * RSB;
         int ntx = tx + 1, nty = ty;
         if (ntx == NTY) { ntx = 0; ++nty; }
-        const bool last = tap + 1 == NT;
-        const int ntapoff = last ? tapoff : (nty * htw + ntx) * RSB;
+        const bool last = tap + 1 == NTOT;
+        const int nt = tap + 1;
+        const int ntapoff = last ? tapoff
+                          : (KIND == 4) ? (((nt >> 3) + ((nt >> 1) & 1)) * htw + ((nt >> 2) & 1) + (nt & 1)) * RSB
+                                        : (nty * htw + ntx) * RSB;
         const bf16_t* wnext = wbase + (size_t)(last ? tap : tap + 1) * tapstride;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -254,12 +261,25 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
           __builtin_amdgcn_sched_barrier(0);
         }
         tx = ntx; ty = nty;
+        if constexpr (KIND == 4) if ((tap & 3) == 3) {
+          // one output parity is complete: through its OWN staging region (the input tile stays for the next parity)
+          par = tap >> 2; py = par >> 1; px = par & 1;
+          float* ot = reinterpret_cast<float*>(tile + ((NP * RSB + 7) & ~7));
+          conv_epilogue<MB, KIND, true>(p, acc, ot + MT * 36, ot, par, py, px, at.img0, at.tin, at.y0, at.x0, wm, wn, lane, h, tid, wave);
+          __syncthreads();  // the staging region is read out before the next parity writes it
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+        }
       }
     }
-    __builtin_amdgcn_s_setprio(2);
-    __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
-    conv_epilogue<MB, KIND, true>(p, acc, smem + MT * 36, smem, par, py, px, at.img0, at.tin, at.y0, at.x0, wm, wn, lane, h, tid, wave);
-    __syncthreads();  // output staging / reduction words are free again for the next tile
+    if constexpr (KIND != 4) {
+      __builtin_amdgcn_s_setprio(2);
+      __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
+      conv_epilogue<MB, KIND, true>(p, acc, smem + MT * 36, smem, par, py, px, at.img0, at.tin, at.y0, at.x0, wm, wn, lane, h, tid, wave);
+    }
+    __syncthreads();  // output staging / reduction words (KIND 4: the input tile) are free again for the next tile
   }
 }
 
@@ -386,6 +406,45 @@ __global__ __launch_bounds__(256) void final_conv_bf16_kernel(const bf16_t* __re
   const int LP = V < 64 ? V : 64;
   const int ppp = 256 / LP;
   const int q = threadIdx.x % LP;
+  if (C == 64) {
+    // C = 64 (as final_conv_kernel): 16 lanes per pixel, 4 pixels per thread and slab, a slab's four loads issued together
+    // and the next slab's before the current one is reduced; table entries and weights in registers
+    const int c = q * 4, p0 = threadIdx.x >> 4;
+    const float4 mu = *reinterpret_cast<const float4*>(s_mean + c);
+    const float4 sc = *reinterpret_cast<const float4*>(s_scale + c);
+    const float4 be = *reinterpret_cast<const float4*>(s_beta + c);
+    float4 wv[4];
+#pragma unroll
+    for (int co = 0; co < 4; ++co) wv[co] = (co < Cout) ? *reinterpret_cast<const float4*>(s_w + co * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bf16_t* ub = u + ((size_t)n * HW + pixb + p0) * C + c;
+    uint2 cur[4], nxt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cur[k] = *reinterpret_cast<const uint2*>(ub + (size_t)(16 * k) * C);
+    for (int sl = 0; sl < slabs; ++sl) {
+      const int sn = (sl + 1 < slabs) ? sl + 1 : sl;  // (clamped: the last prefetch re-reads valid data, unused)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) nxt[k] = *reinterpret_cast<const uint2*>(ub + (size_t)(sn * 64 + 16 * k) * C);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float4 v;  // u3 is stored as half (normalised here)
+        v.x = dm_silu((h2f((bf16_t)(cur[k].x & 0xffffu)) - mu.x) * sc.x + be.x);
+        v.y = dm_silu((h2f((bf16_t)(cur[k].x >> 16)) - mu.y) * sc.y + be.y);
+        v.z = dm_silu((h2f((bf16_t)(cur[k].y & 0xffffu)) - mu.z) * sc.z + be.z);
+        v.w = dm_silu((h2f((bf16_t)(cur[k].y >> 16)) - mu.w) * sc.w + be.w);
+#pragma unroll
+        for (int co = 0; co < 4; ++co) {
+          if (co < Cout) {
+            float sm = v.x * wv[co].x + v.y * wv[co].y + v.z * wv[co].z + v.w * wv[co].w;
+            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            if (q == 0) out[((size_t)n * Cout + co) * HW + pixb + sl * 64 + p0 + 16 * k] = sm + bias[co];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+    }
+    return;
+  }
   for (int sl = 0; sl < slabs; ++sl) {
   const int pix0 = pixb + sl * 64;
   for (int pp = threadIdx.x / LP; pp < 64; pp += ppp) {
