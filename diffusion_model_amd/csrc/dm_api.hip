@@ -280,8 +280,9 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   if (c.kind == 5) {
     const bool geo1 = g.th_log == 3 && g.tw_log == 4 && g.ni == 1 && c.c1 == 64 && (c.c2 == 0 || c.c2 == 64) && c.cout == 64;  // GEO=1
     const bool geo2 = c.H == 8 && c.W == 8 && g.ni == 2 && c.c1 == 64 && (c.c2 == 0 || c.c2 == 64) && c.cout == 64;  // GEO=2
+    const bool geo3 = g.th_log == 3 && g.tw_log == 4 && g.ni == 1 && c.c1 == 256 && (c.c2 == 0 || c.c2 == 256) && c.cout == 256;  // GEO=3
     return geo1 ? launch_conv_t<2, 5, 64, 1>(a, grid, lds, s) : geo2 ? launch_conv_t<2, 5, 64, 2>(a, grid, lds, s)
-                                                                     : launch_conv_t<2, 5, 64>(a, grid, lds, s);
+         : geo3 ? launch_conv_t<2, 5, 64, 3>(a, grid, lds, s) : launch_conv_t<2, 5, 64>(a, grid, lds, s);
   }
   const bool c64 = c.c1 == 64 && (c.c2 == 0 || c.c2 == 64) && c.cout == 64 && g.ni == 1;  // compile-time geometry (GEO=1)
   if (c.kind == 6) return (c64 && g.th_log == 4 && g.tw_log == 3) ? launch_conv_t<2, 1, 16, 1>(a, grid, lds, s) : launch_conv_t<2, 1, 16>(a, grid, lds, s);

@@ -585,6 +585,13 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
     p.H = 8; p.W = 8; p.h_log = 3; p.w_log = 3; p.tiles_per_img = 1; p.tiles_x = 1; p.tpi_log = 0; p.tx_log = 0;
     p.C1 = 64; p.c1_log = 6; p.c2_log = 6; p.Cout = 64; p.cout_log = 6; p.g_log = 3; p.g1_log = 3;
   }
+  if constexpr (GEO == 3) {  // KIND 5, the widened model (BASELINE configs[4]): GEO = 1's tile, 256 channels per pointer and 256 outputs
+    static_assert(MB == 2 && KIND == 5, "GEO=3 instantiation");
+    p.th_log = 3; p.tw_log = 4; p.ni = 1; p.hth = 10; p.htw = 18;
+    p.mg_htw = (unsigned)((0x100000000ull + 17) / 18); p.mg_hth = (unsigned)((0x100000000ull + 9) / 10);
+    p.ppp_q = 0; p.ppp_r = 16;
+    p.C1 = 256; p.c1_log = 8; p.c2_log = 8; p.Cout = 256; p.cout_log = 8; p.g_log = 5; p.g1_log = 5;
+  }
   if constexpr (GEO == 1) {
     // 128-pixel tiles of one image: 8x16 (3x3 and transposed convs: halo 10x18, the fused transposed conv
     // included) or 16x8 outputs of the stride-2 conv (halo 34x18); 64 channels per input pointer, 64 outputs

@@ -281,3 +281,34 @@ def test_attention_fused_kernel(B, T, C):
     assert (o.cpu() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
     rc = L.dm_attention(_lib.ptr(qd), _lib.ptr(o), B, 96, C, torch.cuda.current_stream().cuda_stream)
     assert rc != 0 and b"fused kernel" in L.dm_last_error()
+
+
+def test_steps_not_dividing_T_and_too_many_steps(golden, model, sd):
+    """schedulers.py:146: stride T//n.  n=30 gives 34 ascending steps (golden timesteps_30 holds the reference's list);
+    n > T gives stride 0, which torch.arange rejects in the reference and here alike."""
+    sched = d.DDPMScheduler()
+    smp = d.DDIMSampler(sched, num_inference_steps=30, eta=0.0)
+    assert torch.equal(sched.timesteps.cpu(), golden["timesteps_30"]) and sched.timesteps.numel() == 31
+    x_T = golden["ddim50_x_T"]
+    for use_graph in (True, False):
+        smp.use_graph = use_graph
+        out = smp.sample_from(model, x_T).cpu()
+        ref = O.sample(sd, O.make_schedule(), x_T.shape, 30, 0.0, x_T=x_T)
+        assert (out - ref).abs().max().item() <= 1e-3
+    with pytest.raises(RuntimeError):
+        d.DDIMSampler(d.DDPMScheduler(), num_inference_steps=2000)
+
+
+def test_cosine_schedule_sampling_and_ragged_batches(model, sd):
+    """Cosine betas (schedulers.py:65-72) through the whole loop; batch sizes that leave partial image groups in the
+    multi-image tiles of the low-resolution layers (ni = 2 at 8x8, 4 at 4x4) and a batch of one."""
+    sched = d.DDPMScheduler(beta_schedule="cosine")
+    osch = O.make_schedule(beta_schedule="cosine")
+    smp = d.DDIMSampler(sched, num_inference_steps=8, eta=0.3)
+    for B in (1, 3, 7):
+        g = torch.Generator().manual_seed(100 + B)
+        x_T = torch.randn((B, 1, 32, 32), generator=g)
+        nz = torch.randn((8, B, 1, 32, 32), generator=g)
+        out = smp.sample_from(model, x_T, nz).cpu()
+        ref = O.sample(sd, osch, x_T.shape, 8, 0.3, x_T=x_T, noises=nz)
+        assert (out - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item()), B
