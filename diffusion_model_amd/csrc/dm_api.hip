@@ -263,7 +263,8 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), (c.kind == 2 && !fused_up) ? 4u : 1u);
   a.ntiles = (int)grid.x;
   {  // persistent kernels: at most 3 (Winograd: 2) resident workgroups per CU
-    const unsigned slots = (c.kind == 5 ? 2u : 3u) * cu_count(current_device());  // (measured: 2 vs 3 per CU for the direct kernels is a wash)
+    static const unsigned slot_div = getenv("DM_DEBUG_SLOT_DIV") ? (unsigned)atoi(getenv("DM_DEBUG_SLOT_DIV")) : 1u;  // diagnostics only
+    const unsigned slots = (c.kind == 5 ? 2u : 3u) * cu_count(current_device()) / (slot_div ? slot_div : 1u);  // (measured: 2 vs 3 per CU for the direct kernels is a wash)
     const unsigned resident = slots / (grid.y * grid.z) ? slots / (grid.y * grid.z) : 1u;
     if (grid.x > resident) grid.x = resident;
     a.ngroups = groups;

@@ -784,7 +784,11 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
       // comparisons per element below instead of testing one bit)
       asm volatile("" : "+v"(inbm));
       if (tf && chunk == 0) {
-        gn_tables(p, step_now, img0, tq, s_scale, s_shift, s_temb);  // while the tile loads are in flight
+        // (a fresh opaque copy of the thread id: the table addresses are formed HERE, after the loads were issued;
+        //  formed earlier they sit in registers across the 13 loads and are spilled - 6 dwords per thread and tile)
+        int tg = threadIdx.x;
+        asm volatile("" : "+v"(tg));
+        gn_tables(p, step_now, img0, tg, s_scale, s_shift, s_temb);  // while the tile loads are in flight
         __syncthreads();
       }
       // three straight-line variants (the uniform conditions are hoisted out of the element loop)
@@ -996,7 +1000,10 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) a0[mb] = *reinterpret_cast<const float4*>(tile + abase[mb]);
     int ty = 0, tx = 0;
-#pragma unroll 1
+    // compile-time geometry: the taps are unrolled, so every LDS offset is an immediate and no index math runs
+    // between the MFMAs (as in the Winograd K loop); run-time geometry keeps the rolled loop
+    constexpr int TAP_UNROLL = (GEO == 1 && KIND == 1) ? NTOT : 1;  // (KIND 4: any unrolling spills - 4 taps: 202 registers)
+#pragma unroll TAP_UNROLL
     for (int tap = 0; tap < NTOT; ++tap) {
       // KIND 4: tap = parity*4 + (ty*2+tx); parity (py,px) reads halo rows py+ty, columns px+tx
       const int tapoff = (KIND == 4) ? (((tap >> 3) + ((tap >> 1) & 1)) * htw + ((tap >> 2) & 1) + (tap & 1)) * RS

@@ -95,3 +95,25 @@ def test_bench_kernel_class_names_match_header_enum():
     names = re.search(r"K_NAMES = \[(.*?)\]", src, re.S).group(1).count('"') // 2
     assert names == enum["DM_K_COUNT"]
     assert enum["DM_K_WINO"] == 10 and "K_WINO = 10" in src
+
+
+def test_round2_entry_points_argument_checks_and_sizes():
+    """Host-only behaviour of the entry points added in round 2 (no compute call)."""
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.dm_unet_create(C.byref(h), 1, 1, 64, 128))
+    base = L.dm_sample_workspace_bytes(h, 16, 32, 32, 50, 0, 0)
+    assert base >= L.dm_unet_workspace_bytes(h, 16, 32, 32, 50)
+    with_noise = L.dm_sample_workspace_bytes(h, 16, 32, 32, 50, 0, 1)
+    assert with_noise - base >= 50 * 16 * 1024 * 4          # one 50-step chunk of noise
+    assert L.dm_sample_workspace_bytes(h, 16, 32, 32, 1000, 0, 1) - L.dm_sample_workspace_bytes(h, 16, 32, 32, 1000, 0, 0) \
+        < 51 * 16 * 1024 * 4 + 4096                          # still one chunk, not all 1000 steps
+    assert L.dm_sample_workspace_bytes(h, 16, 32, 32, 50, 1, 0) > 1.9 * base - (1 << 20)  # guided: doubled denoiser batch
+    # statistics buffers hold 4 partials per image at 8x8 (ADVICE r1): the workspace grows accordingly
+    assert L.dm_unet_workspace_bytes(h, 64, 8, 8, 1) >= 2 * 64 * 4 * 16 * 4
+    assert L.dm_noalloc_scratch_bytes() == 64 << 20
+    assert L.dm_unet_forward_noalloc(h, None, None, None, 1, None, None, 1, 32, 32, None) != 0
+    assert L.dm_sampler_step_batched(None, None, None, None, None, 2, 1024, None) != 0 and b"null" in L.dm_last_error()
+    assert L.dm_attention(None, None, 1, 64, 64, None) != 0 and b"null" in L.dm_last_error()
+    assert L.dm_final_conv(None, None, 1, 1.0, None, None, None, None, None, 1, 32, 32, 64, 1, None) != 0
+    L.dm_unet_destroy(h)
