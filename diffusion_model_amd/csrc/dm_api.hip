@@ -4,6 +4,7 @@
 // (diffusion/sampler.py:45-76,136-172).  No torch types; plain pointers and sizes.
 #include "dm_kernels.hip"
 #include "dm_kernels_bf16.hip"
+#include "dm_kernels_x6.hip"
 #include "../../include/dm_sampler.h"
 
 #include <hip/hip_runtime.h>
@@ -122,6 +123,9 @@ ConvGeo conv_geo(int kind, int H, int W, int Cout) {
 unsigned long long* g_stamps = nullptr;  // diagnostic build: set through dm_debug_set_stamps
 #endif
 
+#ifndef DM_X6_DEFAULT
+#define DM_X6_DEFAULT 3
+#endif
 struct ConvCall {
   int kind;
   const float* x1; int c1;
@@ -136,6 +140,7 @@ struct ConvCall {
   int B, H, W;
   const float* res; int no_silu;
   int bf16;  // activations and packed weights are bf16 (conv_bf16_kernel)
+  int x6;    // fp32 activations, weights packed as three bf16 split terms (conv_x6_kernel); kinds 0, 1/6, 2
   const float* init_x; const float* init_w; const float* init_b; int init_cin;  // folded init_conv
 };
 
@@ -183,7 +188,95 @@ int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
   return 0;
 }
 
+template <int MB, int KIND>
+int launch_conv_x6_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_done[DM_MAX_DEVICES] = {false};
+  const int dev = current_device();
+  if (!attr_done[dev]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MB, KIND>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done[dev] = true;
+  }
+  constexpr bool UP = (KIND == 4);
+  const int cls = KIND == 0 ? (MB == 2 ? DM_K_CONV3_128 : DM_K_CONV3_64) : KIND == 1 ? DM_K_DOWN : (MB == 2 ? DM_K_UP_128 : DM_K_UP_64);
+  const double opix = (double)a.B * a.Hb * a.Wb * (UP ? 4 : 1);
+  const double ipix = (double)a.B * a.H * a.W;
+  const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : 4;
+  const int cin = a.C1 + a.C2;
+  ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 4.0 * (ipix * cin + opix * a.Cout) + 6.0 * taps * (UP ? 4 : 1) * cin * a.Cout);
+  hipLaunchKernelGGL((conv_x6_kernel<MB, KIND>), grid, dim3(256), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// The fp32 convolutions on the bf16 matrix pipe (three-way split operands, conv_x6_kernel).  Same tile
+// decomposition (hence the same GroupNorm partial counts) as the other arithmetic variants.
+int launch_conv_x6(const ConvCall& c, hipStream_t s) {
+  const int cin = c.c1 + c.c2;
+  int kind = c.kind == 6 ? 1 : c.kind;
+  if (kind != 0 && kind != 1 && kind != 2) return fail("conv (split-bf16): kind %d is not 3x3 / 4x4 stride 2 / transposed 4x4", c.kind);
+  if (c.res || c.init_x) return fail("conv (split-bf16): no residual / folded init_conv variant");
+  if (c.c1 % 64 || c.c2 % 64 || c.cout % 64 || !is_pow2(c.c1) || (c.c2 && !is_pow2(c.c2)) || !is_pow2(c.cout))
+    return fail("conv (split-bf16): channel counts must be powers of two >= 64 (got %d+%d -> %d)", c.c1, c.c2, c.cout);
+  if (!is_pow2(c.H) || !is_pow2(c.W)) return fail("conv: spatial dims must be powers of two (got %dx%d)", c.H, c.W);
+  if (kind == 1 && (c.H < 2 || c.W < 2)) return fail("conv: stride-2 conv needs H,W >= 2");
+  if (c.stats_in && c.c2) return fail("conv: input transform and channel concat are exclusive");
+  if (c.B <= 0) return fail("conv: empty batch");
+  if (kind == 2 && (c.H * c.W < 16 || cin != 64)) return fail("conv (split-bf16): transposed conv needs >= 16 input pixels and 64 input channels");
+  ConvGeo g = conv_geo(c.kind, c.H, c.W, c.cout);
+  if (c.stats_out && c.stats_cap && (size_t)c.B * g.pout * DM_GROUPS * 2 > c.stats_cap)
+    return fail("conv: statistics buffer too small (%zu floats for %d images x %d partials)", c.stats_cap, c.B, g.pout);
+  const int th = 1 << g.th_log, tw = 1 << g.tw_log;
+  if (kind == 1) { g.hth = th + 1; g.htw = tw + 1; }        // one input phase at a time: (th+1) x (tw+1) pixels
+  if (kind == 2) { g.hth = th + 2; g.htw = tw + 2; }        // all four parities from one tile
+  ConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.x1 = c.x1; a.x2 = c.x2; a.wp = c.wp; a.bias = c.bias; a.y = c.y;
+  a.stats_in = c.stats_in; a.gamma = c.gamma; a.beta = c.beta; a.temb = c.temb;
+  a.step_ptr = c.step_ptr; a.stats_out = c.stats_out; a.cnt_in = c.cnt_in; a.pin = c.pin;
+  a.temb_stride = c.temb_stride; a.temb_step_stride = c.temb_step_stride; a.step_off = c.step_off;
+  a.B = c.B; a.H = c.H; a.W = c.W; a.C1 = c.c1; a.C2 = c.c2; a.Cout = c.cout;
+  a.Hb = g.Hb; a.Wb = g.Wb; a.th_log = g.th_log; a.tw_log = g.tw_log; a.ni = g.ni;
+  a.tiles_x = g.tiles_x; a.tiles_per_img = g.tiles_per_img; a.hth = g.hth; a.htw = g.htw;
+  a.mg_htw = (unsigned)((0x100000000ull + g.htw - 1) / g.htw);
+  a.mg_hth = (unsigned)((0x100000000ull + g.hth - 1) / g.hth);
+  a.pout = g.pout;
+  a.tf_silu = c.no_silu ? 0 : 1;
+  a.h_log = ilog2(c.H); a.w_log = ilog2(c.W); a.c1_log = ilog2(c.c1); a.c2_log = c.c2 ? ilog2(c.c2) : 0;
+  a.cout_log = ilog2(c.cout);
+  a.tpi_log = ilog2(g.tiles_per_img); a.tx_log = ilog2(g.tiles_x);
+  a.g_log = ilog2(c.cout / DM_GROUPS);
+  a.g1_log = ilog2(c.c1 / DM_GROUPS);
+  (void)cin;
+  const size_t np = (size_t)g.ni * g.hth * g.htw;
+  if (np * 8 > 6 * 256 * 4) return fail("conv (split-bf16): tile of %zu halo pixels is too large", np);
+  const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
+  size_t lds_f = (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (3 * np * 72 + 1) / 2 + (kind == 2 ? 128 : 0);
+  if (lds_f < epi_f) lds_f = epi_f;
+  const size_t lds = lds_f * sizeof(float);
+  if (lds > 160 * 1024) return fail("conv (split-bf16): tile needs %zu B of LDS (> 160 KiB)", lds);
+  const int groups = (c.B + g.ni - 1) / g.ni;
+  dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), 1u);
+  a.ntiles = (int)grid.x;
+  {
+    static const unsigned slot_div = getenv("DM_DEBUG_SLOT_DIV") ? (unsigned)atoi(getenv("DM_DEBUG_SLOT_DIV")) : 1u;  // diagnostics only
+    const unsigned per_cu = lds > 80 * 1024 ? 1u : 2u;
+    const unsigned slots = per_cu * cu_count(current_device()) / (slot_div ? slot_div : 1u);
+    const unsigned resident = slots / grid.y ? slots / grid.y : 1u;
+    if (grid.x > resident) grid.x = resident;
+    a.ngroups = groups;
+    a.xcd_map = (grid.x % 8 == 0 && grid.y == 1 && groups >= 64) ? 1 : 0;
+  }
+#ifdef DM_STAMPS
+  a.stamps = g_stamps;
+#endif
+  if (kind == 0) return g.MT == 128 ? launch_conv_x6_t<2, 0>(a, grid, lds, s) : launch_conv_x6_t<1, 0>(a, grid, lds, s);
+  if (kind == 1) return g.MT == 128 ? launch_conv_x6_t<2, 1>(a, grid, lds, s) : launch_conv_x6_t<1, 1>(a, grid, lds, s);
+  return g.MT == 128 ? launch_conv_x6_t<2, 4>(a, grid, lds, s) : launch_conv_x6_t<1, 4>(a, grid, lds, s);
+}
+
 int launch_conv(const ConvCall& c, hipStream_t s) {
+  if (c.x6) return launch_conv_x6(c, s);
   const int cin = c.c1 + c.c2;
   if (c.kind < 0 || (c.kind > 3 && c.kind != 5 && c.kind != 6)) return fail("conv: unknown kind %d", c.kind);
   if (c.kind == 6 && (c.bf16 || (c.H / 2) * (c.W / 2) < 128)) return fail("conv: the 128-pixel-tile stride-2 variant is fp32, for outputs of >= 128 pixels");
@@ -299,6 +392,10 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
 }
 
 size_t conv_packed_floats(int kind, int cin, int cout) {
+  if (kind >= 7 && kind <= 9) {  // split-bf16 form of kinds 0, 1, 2: three bf16 terms per weight
+    const int taps = kind == 7 ? 9 : 16;
+    return ((size_t)taps * cin * cout * 3 + 1) / 2;
+  }
   if (kind == 6) kind = 1;  // same packed weights
   const int taps = kind == 0 ? 9 : kind == 3 ? 1 : 16;  // KIND 2: 4 parities x 4 taps; KIND 5: 16 transform points
   return (size_t)taps * cin * cout;
@@ -307,6 +404,13 @@ size_t conv_packed_floats(int kind, int cin, int cout) {
 int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream_t s, int bf16 = 0) {
   if (kind == 6) kind = 1;
   if (cin % 16 || cout % 32) return fail("pack_conv: cin %% 16 / cout %% 32");
+  if (kind >= 7 && kind <= 9) {
+    const size_t total = (size_t)(kind == 7 ? 9 : 16) * cin * cout;
+    hipLaunchKernelGGL(pack_conv_weight_x6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind - 7, w, cin, cout,
+                       reinterpret_cast<bf16_t*>(out), total);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const size_t total = conv_packed_floats(kind, cin, cout);
   if (bf16) {
     if (kind == 3 || kind == 5) return fail("pack_conv: no bf16 1x1 / Winograd variant");
@@ -324,7 +428,7 @@ int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream
 }  // namespace
 
 // ------------------------------------------------------------------ model container
-struct BlockOff { size_t tmw, tmb, c1, c1b, c2, c2b, tr, trb, g1, b1, g2, b2, c1w, c2w; };  // c1w/c2w: Winograd form
+struct BlockOff { size_t tmw, tmb, c1, c1b, c2, c2b, tr, trb, g1, b1, g2, b2, c1w, c2w, c1x, c2x, trx; };  // c1w/c2w: Winograd form; *x: split-bf16 form
 
 // A captured chunk of S sampling steps.  The nodes hold workspace addresses only (dm_sample stages
 // x, timesteps, coefficients, class embeddings and noise into the workspace), so the key is the
@@ -342,11 +446,13 @@ struct AttnOff { size_t ng, nb, qkv, qkvb, proj, projb; };
 struct dm_unet {
   int Cin, Cout, C, E;
   int bf16;            // 1: bf16 activations + conv weights (fp32 accumulate / statistics)
+  int x6;              // fp32 path: which convolutions run on the bf16 pipe with three-way split operands (conv_x6_kernel):
+                       // bit 0 stride-2 4x4, bit 1 transposed 4x4, bit 2 3x3 below 8x8, bit 3 every 3x3
   int attn;            // build-defined attention blocks at 1/4 resolution (after down2 and up1)
   AttnOff att[2];
   size_t o_freqs, o_tm1w, o_tm1b, o_tm2w, o_tm2b, o_initw, o_initb;
   BlockOff blk[6];
-  size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb, o_b0w, o_b3w;
+  size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb, o_b0w, o_b3w, o_b0x, o_b3x;
   size_t total;
   std::vector<GraphEntry> graphs;
 };
@@ -553,7 +659,8 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   const int C = m->C;
   // init_conv (model.py:135) is folded into down1.conv1's staging (no kernel, no HBM round trip)
   // (also in bf16: the stand-alone init kernel + a plain first layer take 343 + 163 us at B = 2048, the folded layer 420)
-  const bool fold_init = true;
+  const int x6 = m->bf16 ? 0 : m->x6;
+  const bool fold_init = !(x6 & 8);  // (the split-bf16 3x3 kernel has no folded-init staging: stand-alone init kernel)
   if (!fold_init) {
     const size_t lds = (size_t)m->Cin * 9 * C * sizeof(float);
     const size_t total = (size_t)B * H * W * (C / 4);
@@ -579,22 +686,29 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   };
   // Block.forward (model.py:52-64); in: block input(s) at hxw
   // 3x3 convolutions: Winograd F(2x2,3x3) in fp32 from 8x8 up, the direct form below that and in bf16
-  auto k3 = [&](int h, int ww) { return (!m->bf16 && h >= 8 && ww >= 8) ? 5 : 0; };
+  // (split-bf16 form, conv_x6_kernel: where m->x6 selects it)
+  auto x3 = [&](int h, int ww) { return (x6 & 8) || ((x6 & 4) && (h < 8 || ww < 8)); };
+  auto k3 = [&](int h, int ww) { return (!m->bf16 && !x3(h, ww) && h >= 8 && ww >= 8) ? 5 : 0; };
   auto block = [&](int k, const float* in1, const float* in2, int h, int ww, bool up, float* out, float* out_stats) -> int {
     const BlockOff& o = m->blk[k];
     const int kd = k3(h, ww);
-    base(kd, in1, C, in2, in2 ? C : 0, kd == 5 ? o.c1w : o.c1, o.c1b, w.T1, w.SA, h, ww);
+    const bool xs = x3(h, ww);
+    base(kd, in1, C, in2, in2 ? C : 0, xs ? o.c1x : kd == 5 ? o.c1w : o.c1, o.c1b, w.T1, w.SA, h, ww);
+    c.x6 = xs;
     if (k == 0 && fold_init) {
       c.init_x = x; c.init_w = P + m->o_initw; c.init_b = P + m->o_initb; c.init_cin = m->Cin;
     }
     if (launch_conv(c, s)) return 1;
-    base(kd, w.T1, C, nullptr, 0, kd == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
+    base(kd, w.T1, C, nullptr, 0, xs ? o.c2x : kd == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
+    c.x6 = xs;
     with_tf(w.SA, kd, h, ww, o.g1, o.b1);
     c.temb = heads + (size_t)k * C; c.temb_stride = heads_img_stride; c.temb_step_stride = heads_step_stride;
     c.step_ptr = step_ptr; c.step_off = step_off;
     if (launch_conv(c, s)) return 1;
     const int kdn = (!m->bf16 && (h / 2) * (ww / 2) >= 256) ? 6 : 1;  // stride-2 conv: 128-pixel tiles from 16x16 outputs up
-    base(up ? 2 : kdn, w.T2, C, nullptr, 0, o.tr, o.trb, out, out_stats, h, ww);
+    const bool xt = up ? ((x6 & 2) && h * ww >= 16 && C == 64) : (x6 & 1) != 0;  // (transposed: single K chunk only)
+    base(up ? 2 : kdn, w.T2, C, nullptr, 0, xt ? o.trx : o.tr, o.trb, out, out_stats, h, ww);
+    c.x6 = xt;
     with_tf(w.SB, kd, h, ww, o.g2, o.b2);
     return launch_conv(c, s);
   };
@@ -607,9 +721,12 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   if (block(2, w.D2, nullptr, H / 4, W / 4, false, w.D3, nullptr)) return 1;
   // bottleneck (model.py:98-103,143)
   const int kb = k3(H / 8, W / 8);
-  base(kb, w.D3, C, nullptr, 0, kb == 5 ? m->o_b0w : m->o_b0, m->o_b0b, w.BT0, w.SA, H / 8, W / 8);
+  const bool xb = x3(H / 8, W / 8);
+  base(kb, w.D3, C, nullptr, 0, xb ? m->o_b0x : kb == 5 ? m->o_b0w : m->o_b0, m->o_b0b, w.BT0, w.SA, H / 8, W / 8);
+  c.x6 = xb;
   if (launch_conv(c, s)) return 1;
-  base(kb, w.BT0, C, nullptr, 0, kb == 5 ? m->o_b3w : m->o_b3, m->o_b3b, w.BT, nullptr, H / 8, W / 8);
+  base(kb, w.BT0, C, nullptr, 0, xb ? m->o_b3x : kb == 5 ? m->o_b3w : m->o_b3, m->o_b3b, w.BT, nullptr, H / 8, W / 8);
+  c.x6 = xb;
   with_tf(w.SA, kb, H / 8, W / 8, m->o_bg, m->o_bb);
   if (launch_conv(c, s)) return 1;
   // up path: channel concat [upstream, skip] (model.py:146-148) handled by two input pointers
@@ -750,6 +867,7 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
   m->Cin = in_channels; m->Cout = out_channels; m->C = model_channels; m->E = time_emb_dim;
   m->attn = attention ? 1 : 0;
   m->bf16 = 0;
+  m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 15 : DM_X6_DEFAULT;
   const int C = m->C, E = m->E;
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
@@ -765,8 +883,11 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
     b.c2 = take(conv_packed_floats(0, C, C)); b.c2b = take(C);
     b.g1 = take(C); b.b1 = take(C); b.g2 = take(C); b.b2 = take(C);
     b.c1w = take(conv_packed_floats(5, up ? 2 * C : C, C)); b.c2w = take(conv_packed_floats(5, C, C));
+    b.c1x = take(conv_packed_floats(7, up ? 2 * C : C, C)); b.c2x = take(conv_packed_floats(7, C, C));
+    b.trx = take(conv_packed_floats(up ? 9 : 8, C, C));
   }
   m->o_b0w = take(conv_packed_floats(5, C, C)); m->o_b3w = take(conv_packed_floats(5, C, C));
+  m->o_b0x = take(conv_packed_floats(7, C, C)); m->o_b3x = take(conv_packed_floats(7, C, C));
   m->o_b0 = take(conv_packed_floats(0, C, C)); m->o_b0b = take(C);
   m->o_bg = take(C); m->o_bb = take(C);
   m->o_b3 = take(conv_packed_floats(0, C, C)); m->o_b3b = take(C);
@@ -822,16 +943,18 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
     const bool up = k >= 3;
     const BlockOff& b = m->blk[k];
     if (copy(b.tmw, p[i++], (size_t)C * E) || copy(b.tmb, p[i++], C)) return 1;
-    if (!m->bf16 && pack_conv(5, p[i], up ? 2 * C : C, C, packed + b.c1w, s)) return 1;
+    if (!m->bf16 && (pack_conv(5, p[i], up ? 2 * C : C, C, packed + b.c1w, s) || pack_conv(7, p[i], up ? 2 * C : C, C, packed + b.c1x, s))) return 1;
     if (pack_conv(0, p[i++], up ? 2 * C : C, C, packed + b.c1, s, m->bf16) || copy(b.c1b, p[i++], C)) return 1;
+    if (!m->bf16 && pack_conv(up ? 9 : 8, p[i], C, C, packed + b.trx, s)) return 1;
     if (pack_conv(up ? 2 : 1, p[i++], C, C, packed + b.tr, s, m->bf16) || copy(b.trb, p[i++], C)) return 1;
-    if (!m->bf16 && pack_conv(5, p[i], C, C, packed + b.c2w, s)) return 1;
+    if (!m->bf16 && (pack_conv(5, p[i], C, C, packed + b.c2w, s) || pack_conv(7, p[i], C, C, packed + b.c2x, s))) return 1;
     if (pack_conv(0, p[i++], C, C, packed + b.c2, s, m->bf16) || copy(b.c2b, p[i++], C)) return 1;
     if (copy(b.g1, p[i++], C) || copy(b.b1, p[i++], C) || copy(b.g2, p[i++], C) || copy(b.b2, p[i++], C)) return 1;
     return 0;
   };
   for (int k = 0; k < 3; ++k) if (do_block(k)) return 1;
-  if (!m->bf16 && (pack_conv(5, p[i], C, C, packed + m->o_b0w, s) || pack_conv(5, p[i + 4], C, C, packed + m->o_b3w, s))) return 1;
+  if (!m->bf16 && (pack_conv(5, p[i], C, C, packed + m->o_b0w, s) || pack_conv(5, p[i + 4], C, C, packed + m->o_b3w, s) ||
+                   pack_conv(7, p[i], C, C, packed + m->o_b0x, s) || pack_conv(7, p[i + 4], C, C, packed + m->o_b3x, s))) return 1;
   if (pack_conv(0, p[i++], C, C, packed + m->o_b0, s, m->bf16) || copy(m->o_b0b, p[i++], C) ||
       copy(m->o_bg, p[i++], C) || copy(m->o_bb, p[i++], C) ||
       pack_conv(0, p[i++], C, C, packed + m->o_b3, s, m->bf16) || copy(m->o_b3b, p[i++], C)) return 1;
@@ -1104,12 +1227,16 @@ size_t dm_conv_packed_floats(int kind, int cin, int cout) { return conv_packed_f
 
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev, void* stream) {
   if (!w_dev || !packed_dev) return fail("dm_pack_conv_weight: null argument");
-  if (kind < 0 || (kind > 3 && kind != 5 && kind != 6)) return fail("unknown conv kind %d", kind);
+  if (kind < 0 || kind == 4 || kind > 9) return fail("unknown conv kind %d", kind);
   return pack_conv(kind, w_dev, cin, cout, packed_dev, (hipStream_t)stream);
 }
 
+// kinds 7, 8, 9: kinds 0, 1 (on 128-pixel tiles from 256 output pixels up, as the model does) and 2 in the split-bf16 form
+static int x6_base_kind(int kind, int H, int W) { return kind == 7 ? 0 : kind == 9 ? 2 : ((H / 2) * (W / 2) >= 256 ? 6 : 1); }
+
 int dm_conv_stats_partials(int kind, int H, int W) {
-  if (kind < 0 || (kind > 3 && kind != 5 && kind != 6) || !is_pow2(H) || !is_pow2(W)) return 0;
+  if (kind < 0 || kind == 4 || kind > 9 || !is_pow2(H) || !is_pow2(W)) return 0;
+  if (kind >= 7) kind = x6_base_kind(kind, H, W);
   return conv_geo(kind, H, W, 64).pout;
 }
 
@@ -1124,6 +1251,7 @@ int dm_conv2d(int kind, const float* x1, int c1, const float* x2, int c2, const 
   c.kind = kind; c.x1 = x1; c.c1 = c1; c.x2 = c2 ? x2 : nullptr; c.c2 = c2; c.wp = wp; c.bias = bias; c.cout = cout;
   c.stats_in = stats_in; c.pin = pin; c.cnt_in = cnt_in; c.gamma = gamma; c.beta = beta;
   c.temb = temb; c.temb_stride = temb_stride; c.y = y; c.stats_out = stats_out; c.B = B; c.H = H; c.W = W;
+  if (kind >= 7 && kind <= 9) { c.x6 = 1; c.kind = x6_base_kind(kind, H, W); }
   return launch_conv(c, (hipStream_t)stream);
 }
 

@@ -13,6 +13,13 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// wave priorities of the staging/epilogue phases and of the K loop (s_setprio; overridable for diagnostic builds)
+#ifndef DM_PRIO_STAGE
+#define DM_PRIO_STAGE 2
+#endif
+#ifndef DM_PRIO_K
+#define DM_PRIO_K 0
+#endif
 #define DM_GROUPS 8
 #define DM_GN_EPS 1e-5f
 
@@ -116,15 +123,23 @@ struct ConvArgs {
 #endif
 };
 
-#ifdef DM_STAMPS
+#if defined(DM_STAMPS) && !defined(DM_TIMELINE)
 #define DM_STAMP(k) do { if (p.stamps && threadIdx.x == 0) { size_t o_ = ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; p.stamps[o_ + (k)] = __builtin_amdgcn_s_memtime(); if ((k) == 0 || (k) == 3) p.stamps[o_ + 4 + ((k) == 3)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define DM_STAMP(k) do {} while (0)
 #endif
-#ifdef DM_STAMPS
+#if defined(DM_STAMPS) && !defined(DM_TIMELINE)
 #define DM_STAMP_RAW(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define DM_STAMP_RAW(slot) do {} while (0)
+#endif
+
+// -DDM_STAMPS -DDM_TIMELINE (diagnostic build): every workgroup appends (code << 56 | s_memtime) events to its own
+// 128-entry row of the stamps buffer: 1 tile start, 2 K loop start (of a chunk), 5 next chunk's staging starts, 3 K loop end, 4 tile end; entry 0 = XCC/HW id
+#ifdef DM_TIMELINE
+#define DM_TL(code) do { if (p.stamps && threadIdx.x == 0 && tl_n < 126) { p.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 128 + 2 + tl_n] = ((unsigned long long)(code) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); ++tl_n; } } while (0)
+#else
+#define DM_TL(code) do {} while (0)
 #endif
 
 // Epilogue of conv_mfma_kernel for one set of accumulators: + bias; GroupNorm partial statistics;
@@ -568,7 +583,11 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs& p, f32x16 (&acc)[8
   for (int k = 0; k < 8; ++k) {
     const int m = p0 + 16 * k;
     const int x = x0 + (m & (tw - 1)), y = y0 + ((m >> p.tw_log) & (th - 1)), n = img0 + (m >> tsh);
+#ifdef DM_DIAG_NOSTORE
+    if (v[k].x == 1.2345f)
+#else
     if (p.ni == 1 || n < p.B)
+#endif
       *reinterpret_cast<float4*>(p.y + ((((size_t)n * p.H + y) * p.W + x) * p.Cout + blockIdx.y * 64 + c4 * 4)) = v[k];
   }
 }
@@ -619,10 +638,19 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
   const float bias_lane = WINO ? 0.f : p.bias[blockIdx.y * 64 + ((threadIdx.x >> 6) & 1) * 32 + (threadIdx.x & 31)];
 
   DM_STAMP(0);
+#ifdef DM_TIMELINE
+  int tl_n = 0;
+  if (p.stamps && threadIdx.x == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 128] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
   // Staging and epilogue ask for raised wave priority, the K loop for 0.  (Measured effect: small.
   // The fp32 MFMA executes on the SIMD's fp32 lanes, so other waves' VALU work does not overlap
   // it whatever the priority: tools/diag/valu_starve.hip.)
-  __builtin_amdgcn_s_setprio(2);
+  __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -728,6 +756,7 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
   asm volatile("" : "+v"(tq));
   if (KIND == 4) { par = 0; py = 0; px = 0; }  // (advanced by the previous tile's K loop)
   DM_STAMP_RAW(7);  // (diagnostic build) start of this tile: slots 7,1,2,3 bracket the LAST tile's phases
+  DM_TL(1);
   const int img0 = (t >> p.tpi_log) * p.ni;
   const int tin = t & (p.tiles_per_img - 1);
   const int y0 = (tin >> p.tx_log) << p.th_log;
@@ -748,7 +777,8 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
                         (size_t)(blockIdx.y * 2 + wn_s) * 256;
     const float* wbase = wuni + lane * 4;
     if (chunk > 0) {
-      __builtin_amdgcn_s_setprio(2);
+      DM_TL(5);
+      __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
       __syncthreads();
     }  // previous chunk's LDS reads are done
     // ---- stage: global -> (transform) -> LDS, U loads in flight per thread (HBM latency
@@ -777,7 +807,11 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
         // unconditional load from a clamped (always valid) address; padding is a select afterwards
         const int lin = min(max((iy << p.w_log) + ix, 0), hw1);
         const unsigned off = (unsigned)((((p.ni == 1) ? 0 : min(iu, imax)) << (p.h_log + p.w_log)) + lin) << cs_log;
+#ifdef DM_DIAG_NOLOAD
+        v[u] = make_float4((float)off, 1.f, 2.f, 3.f);
+#else
         v[u] = *reinterpret_cast<const float4*>(srcb + off);
+#endif
         inbm |= inb ? (1u << u) : 0u;
       }
       // (opaque: otherwise hipcc keeps the 26 halo coordinates alive - spilled - and redoes the four
@@ -928,9 +962,10 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) bq[j * 2 + nb] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wu5 + (size_t)(j * nb32 + nb) * 256) + lane16);
       __syncthreads();
-      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(DM_PRIO_K);
       if (chunk == 0) {
         DM_STAMP(1);
+        DM_TL(2);
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
@@ -953,11 +988,13 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
           eh[c] = __builtin_elementwise_fma(sg2, dh[4 + c], dh[c]);
         }
         const int gn = (g + 1 < NJ) ? g + 1 : g;  // (clamped: the last prefetch re-reads valid data, unused)
+#ifndef DM_DIAG_NOLDS
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const float4 t4 = *reinterpret_cast<const float4*>(tile + albase + auo[q] + gn * 8);
           dl[q] = f32x2{t4.x, t4.y}; dh[q] = f32x2{t4.z, t4.w};
         }
+#endif
         const float* wnext = wu5 + (size_t)gn * gstride;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -972,7 +1009,9 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
             acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl.y, b.y, acc[j * 2 + nb], 0, 0, 0);
             acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh.x, b.z, acc[j * 2 + nb], 0, 0, 0);
             acc[j * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh.y, b.w, acc[j * 2 + nb], 0, 0, 0);
+#ifndef DM_DIAG_NOB
             bq[j * 2 + nb] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wnext + (size_t)(j * nb32 + nb) * 256) + lane16);
+#endif
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -982,9 +1021,11 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bq[j] = *reinterpret_cast<const float4*>(wbase + j * jstride);
     __syncthreads();
-    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(DM_PRIO_K);
+    if (chunk > 0) DM_TL(2);
     if (chunk == 0) {
       DM_STAMP(1);
+      DM_TL(2);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -1052,7 +1093,8 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
   }
 
   DM_STAMP(2);
-  __builtin_amdgcn_s_setprio(2);
+  DM_TL(3);
+  __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
   if constexpr (WINO) {
     __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
     wino_epilogue(p, acc, smem_b, img0, tin, y0, x0, tq);
@@ -1061,9 +1103,10 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
     conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, (tq >> 7) & 1, (tq >> 6) & 1, tq & 63, (tq >> 5) & 1, tq, tq >> 6, bias_lane, true);
   }
   __syncthreads();  // LDS (output staging / reduction words) is free again for the next tile
+  DM_TL(4);
   }  // tile loop
   DM_STAMP(3);
-#ifdef DM_STAMPS
+#if defined(DM_STAMPS) && !defined(DM_TIMELINE)
   if (p.stamps && threadIdx.x == 0) {
     unsigned hwid, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));

@@ -1,0 +1,340 @@
+// dm_kernels_x6.hip — the fp32 convolutions computed on the bf16 matrix pipe with fp32-equivalent accuracy.
+//
+// gfx950's exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate, and a wave that mixes MFMAs with
+// anything else time-shares its SIMD with the other waves (tools/diag/mfma_coissue.hip), so the fp32 kernels are bound
+// by MFMA time + vector time.  Here every fp32 operand is split into THREE bf16 terms, x = x1 + x2 + x3 with
+// x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (24 mantissa bits: the split is exact to 2^-27 |x|), and a
+// product is taken as  a1 b1 + a1 b2 + a2 b1 + a2 b2 + a1 b3 + a3 b1  — six v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation; the dropped terms are <= 2^-26 |a b|, below the rounding of an fp32 product.  Six bf16 MFMAs cost
+// 6/16 of the fp32 MFMA time for the same K: less than the Winograd form (4/9) and with none of its transforms.
+// tools/diag/bf16x6_sim.py: the result is as close to the fp64 dot product as fp32-MFMA accumulation is.
+//
+// Structure as conv_bf16_kernel: persistent workgroups, XCD-aware tile order, GroupNorm+SiLU+temb applied while the
+// fp32 NHWC input tile is staged — then split and written to LDS as three bf16 planes [plane][halo pixel][KC + 8] —,
+// weights pre-split and packed in B-fragment order [split][parity][tap][Cin/16][Cout/32][64 lanes][8 bf16], fp32
+// accumulators, the fp32 epilogue of conv_mfma_kernel (bias, GroupNorm partials, coalesced NHWC stores).
+//   KIND 0: Conv2d 3x3 s1 p1.
+//   KIND 1: Conv2d 4x4 s2 p1 as four stride-1 2x2 convolutions over the four (row, column) phases of the input
+//           (space-to-depth): one K chunk per phase, so a tile holds (th+1) x (tw+1) pixels of ONE phase at a time
+//           and every global read is a whole 256-byte pixel (the 16-channel chunks of conv_mfma_kernel<2,1,16>
+//           fetched each 128-byte line twice).
+//   KIND 4: ConvTranspose2d 4x4 s2 p1, all four output parities from one staged tile.
+#pragma once
+#include "dm_kernels_bf16.hip"
+
+typedef float dm_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 dm_bf2 __attribute__((ext_vector_type(2)));
+
+// (a, b) -> three packed bf16 pairs; a = lo half.  v_cvt_pk_bf16_f32 rounds to nearest even; the residuals are exact.
+__device__ __forceinline__ void dm_split3(float a, float b, unsigned& s1, unsigned& s2, unsigned& s3) {
+  dm_f2 v = {a, b};
+  s1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, dm_bf2));
+  v -= dm_f2{__uint_as_float(s1 << 16), __uint_as_float(s1 & 0xffff0000u)};
+  s2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, dm_bf2));
+  v -= dm_f2{__uint_as_float(s2 << 16), __uint_as_float(s2 & 0xffff0000u)};
+  s3 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, dm_bf2));
+}
+
+template <int MB, int KIND>
+__global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
+  constexpr int KC = 64;
+  constexpr int MT = 64 * MB;
+  constexpr int RSB = KC + 8;   // LDS row stride in bf16 (144 B: 16-B skew between pixels)
+  constexpr int SS = (KIND == 1) ? 2 : 1;      // input pixels per halo step
+  constexpr int NTY = (KIND == 0) ? 3 : 2;     // taps per axis walked per chunk (KIND 1: 2x2 per phase)
+  constexpr int NT = NTY * NTY;
+  constexpr int NTW = (KIND == 0) ? 9 : (KIND == 1) ? 16 : 4;  // taps per parity in the packed weights
+  constexpr int NTOT = (KIND == 4) ? 16 : NT;
+  constexpr int NJ = KC / 16;
+  constexpr int U = 6;          // staging items (8 channels = two 16-byte loads) per thread and batch
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
+#ifdef DM_TIMELINE
+  int tl_n = 0;
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 128] = 0;
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
+  const int Cin = p.C1 + p.C2;
+  int par = 0, py = 0, px = 0;
+  const int th = 1 << p.th_log, tw = 1 << p.tw_log;
+  const int hth = p.hth, htw = p.htw;
+  const int NP = p.ni * hth * htw;
+  const int items = NP * 8;
+  const int step_now = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
+  const float bias_lane = p.bias[blockIdx.y * 64 + wn * 32 + (lane & 31)];
+
+  const bool tf = p.stats_in != nullptr;
+  float* s_scale = smem;
+  float* s_shift = s_scale + (tf ? p.ni * p.C1 : 0);
+  float* s_temb = s_shift + (tf ? p.ni * p.C1 : 0);
+  bf16_t* tile = reinterpret_cast<bf16_t*>(s_temb + (tf ? p.ni * p.C1 : 0));
+  const int PL = NP * RSB;      // plane stride (bf16 elements; a multiple of 8)
+
+  int abase[MB];  // bf16 offsets of this lane's A fragments at tap (0,0)
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = wm * (32 * MB) + mb * 32 + (lane & 31);
+    const int x = m & (tw - 1);
+    const int y = (m >> p.tw_log) & (th - 1);
+    const int i = m >> (p.tw_log + p.th_log);
+    abase[mb] = ((i * hth + y) * htw + x) * RSB + 8 * h;
+  }
+
+  f32x16 acc[MB];
+  const int nb32 = p.Cout >> 5;
+  const size_t jstride = (size_t)nb32 * 512;               // bf16 elements per (16 channels, all output channels)
+  const size_t tapstride = (size_t)(Cin >> 4) * jstride;
+  const size_t split_off = (size_t)((KIND == 4) ? 4 * NTW : NTW) * tapstride;  // one split term's whole block
+  const int cchunks = Cin / KC;
+  const int nchunks = (KIND == 1) ? 4 * cchunks : cchunks;  // KIND 1: (phase, channel chunk)
+  const bf16_t* wpk = reinterpret_cast<const bf16_t*>(p.wp);
+
+  // first-batch halo coordinates do not depend on the tile: (image << 16 | hy << 8 | hx), once per workgroup
+  int hyx0[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int pix = (u * 256 + tid) >> 3;
+    const int r = __umulhi((unsigned)pix, p.mg_htw);
+    const int i = __umulhi((unsigned)r, p.mg_hth);
+    hyx0[u] = (i << 16) | ((r - i * hth) << 8) | (pix - r * htw);
+  }
+
+  const int t_first = p.xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int t_step = p.xcd_map ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int t_xcd = p.xcd_map ? (int)(blockIdx.x & 7) : 0;
+  const int t_end = p.xcd_map ? (((p.ngroups - t_xcd + 7) >> 3) << p.tpi_log) : p.ntiles;
+  for (int ts = t_first; ts < t_end; ts += t_step) {
+    const int t = p.xcd_map ? (((((ts >> p.tpi_log) << 3) + t_xcd) << p.tpi_log) | (ts & (p.tiles_per_img - 1))) : ts;
+    if (KIND == 4) { par = 0; py = 0; px = 0; }  // (advanced by the previous tile's K loop)
+    const int img0 = (t >> p.tpi_log) * p.ni;
+    const int tin = t & (p.tiles_per_img - 1);
+    const int y0 = (tin >> p.tx_log) << p.th_log;
+    const int x0 = (tin & (p.tiles_x - 1)) << p.tw_log;
+    DM_TL(1);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+      const int cch = (KIND == 1) ? chunk % cchunks : chunk;   // channel chunk
+      const int ph = (KIND == 1) ? chunk / cchunks : 0;        // KIND 1: input phase (row parity a, column parity b)
+      const int pa = ph >> 1, pb = ph & 1;
+      // KIND 1: plane pixel (Y, X) of phase (a, b) is input pixel (2 y0 - a + 2 Y, 2 x0 - b + 2 X); its taps are
+      // ky = 2 ty + 1 - a, kx = 2 tx + 1 - b  (output (y, x) reads input rows 2y - 1 + ky)
+      const int hy0 = (KIND == 1) ? 2 * y0 - pa : y0 - 1;
+      const int hx0 = (KIND == 1) ? 2 * x0 - pb : x0 - 1;
+      const int cg0 = cch * KC;
+      const bool from2 = cg0 >= p.C1;
+      const float* src = from2 ? p.x2 : p.x1;
+      const int cs_log = from2 ? p.c2_log : p.c1_log;
+      const int coff = from2 ? cg0 - p.C1 : cg0;
+      const int wn_s = __builtin_amdgcn_readfirstlane(wn);
+      const bf16_t* wbase = wpk + (size_t)cch * NJ * jstride + (size_t)(blockIdx.y * 2 + wn_s) * 512 + lane * 8;
+      if (chunk > 0) {
+        DM_TL(5);
+        __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
+        __syncthreads();  // previous chunk's LDS reads are done
+      }
+      // ---- stage: global fp32 -> GroupNorm + SiLU + temb -> three bf16 planes in LDS
+      {
+        const int imax = p.B - 1 - img0;
+        const float* srcb = src + ((size_t)img0 << (p.h_log + p.w_log + cs_log)) + coff;
+        for (int base = 0; base < items; base += 256 * U) {  // uniform trip count (barrier inside)
+          int tq = threadIdx.x;  // opaque copy: index math is redone here, not hoisted out of the tile loop and kept live
+          asm volatile("" : "+v"(tq));
+          float4 v0[U], v1[U];
+          unsigned inbm = 0;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int idx = base + u * 256 + tq;
+            const int c8 = idx & 7;
+            int hx, hy, i;
+            if (base == 0) {
+              hx = hyx0[u] & 255; hy = (hyx0[u] >> 8) & 255; i = hyx0[u] >> 16;
+            } else {
+              const int pix = idx >> 3;
+              const int r = __umulhi((unsigned)pix, p.mg_htw);
+              hx = pix - r * htw;
+              i = __umulhi((unsigned)r, p.mg_hth);
+              hy = r - i * hth;
+            }
+            const int iy = hy0 + SS * hy, ix = hx0 + SS * hx;
+            const bool inb = idx < items && i <= imax && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            // unconditional loads from a clamped (always valid) address; padding is a select afterwards
+            const int cn = min(i, imax), cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
+            const unsigned off = ((unsigned)(((cn << p.h_log) + cy) << p.w_log) + cx) << cs_log;
+            const float* q = srcb + off + c8 * 8;
+            v0[u] = *reinterpret_cast<const float4*>(q);
+            v1[u] = *reinterpret_cast<const float4*>(q + 4);
+            inbm |= inb ? (1u << u) : 0u;
+          }
+          asm volatile("" : "+v"(inbm));
+          if (tf && chunk == 0 && base == 0) {
+            int tg = threadIdx.x;
+            asm volatile("" : "+v"(tg));
+            gn_tables(p, step_now, img0, tg, s_scale, s_shift, s_temb);  // while the tile loads are in flight
+            __syncthreads();
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int idx = base + u * 256 + tq;
+            if (idx < items) {
+              const int pix = idx >> 3, c8 = idx & 7;
+              float e[8] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w, v1[u].x, v1[u].y, v1[u].z, v1[u].w};
+              if (!((inbm >> u) & 1)) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] = 0.f;  // zero padding / images past the batch stay exactly 0
+              } else if (tf) {
+                const int i = (p.ni == 1) ? 0 : (base == 0) ? (hyx0[u] >> 16) : (int)__umulhi(__umulhi((unsigned)pix, p.mg_htw), p.mg_hth);
+                const int tofs = (i << p.c1_log) + coff + c8 * 8;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                  const float4 sc = *reinterpret_cast<const float4*>(s_scale + tofs + 4 * q);
+                  const float4 sh = *reinterpret_cast<const float4*>(s_shift + tofs + 4 * q);
+                  const float4 te = *reinterpret_cast<const float4*>(s_temb + tofs + 4 * q);
+                  float4 w = make_float4(fmaf(e[4 * q], sc.x, sh.x), fmaf(e[4 * q + 1], sc.y, sh.y),
+                                         fmaf(e[4 * q + 2], sc.z, sh.z), fmaf(e[4 * q + 3], sc.w, sh.w));
+                  if (p.tf_silu) w = dm_silu_add4(w, te);
+                  else { w.x += te.x; w.y += te.y; w.z += te.z; w.w += te.w; }
+                  e[4 * q] = w.x; e[4 * q + 1] = w.y; e[4 * q + 2] = w.z; e[4 * q + 3] = w.w;
+                }
+              }
+              uint4 s1, s2, s3;
+              dm_split3(e[0], e[1], s1.x, s2.x, s3.x);
+              dm_split3(e[2], e[3], s1.y, s2.y, s3.y);
+              dm_split3(e[4], e[5], s1.z, s2.z, s3.z);
+              dm_split3(e[6], e[7], s1.w, s2.w, s3.w);
+              bf16_t* q = tile + pix * RSB + c8 * 8;
+              *reinterpret_cast<uint4*>(q) = s1;
+              *reinterpret_cast<uint4*>(q + PL) = s2;
+              *reinterpret_cast<uint4*>(q + 2 * PL) = s3;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one item's chain at a time (register peak)
+          }
+        }
+      }
+      // weight tap of (this chunk's) tap index tp: KIND 1 maps the phase's 2x2 taps into the 4x4 kernel
+      auto wtap = [&](int tp) {
+        const int wt = (KIND == 1) ? ((2 * (tp >> 1) + 1 - pa) * 4 + 2 * (tp & 1) + 1 - pb) : tp;
+        return wbase + (size_t)wt * tapstride;
+      };
+      uint4 bq[NJ][3];
+      {
+        const bf16_t* w0 = wtap(0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int s = 0; s < 3; ++s) bq[j][s] = *reinterpret_cast<const uint4*>(w0 + s * split_off + j * jstride);
+      }
+      __syncthreads();
+      __builtin_amdgcn_s_setprio(DM_PRIO_K);
+      DM_TL(2);
+      if (chunk == 0) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+      }
+      uint4 a0[3][MB], a1[3][MB];
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) a0[s][mb] = *reinterpret_cast<const uint4*>(tile + s * PL + abase[mb]);
+      int ty = 0, tx = 0;
+#pragma unroll 1
+      for (int tap = 0; tap < NTOT; ++tap) {
+        // KIND 4: tap = parity*4 + (ty*2+tx); parity (py,px) reads halo rows py+ty, columns px+tx
+        const int tapoff = (KIND == 4) ? (((tap >> 3) + ((tap >> 1) & 1)) * htw + ((tap >> 2) & 1) + (tap & 1)) * RSB
+                                       : (ty * htw + tx) * RSB;
+        int ntx = tx + 1, nty = ty;
+        if (ntx == NTY) { ntx = 0; ++nty; }
+        const bool last = tap + 1 == NTOT;
+        const int nt = tap + 1;
+        const int ntapoff = last ? tapoff
+                          : (KIND == 4) ? (((nt >> 3) + ((nt >> 1) & 1)) * htw + ((nt >> 2) & 1) + (nt & 1)) * RSB
+                                        : (nty * htw + ntx) * RSB;
+        const bf16_t* wnext = wtap(last ? tap : tap + 1);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          uint4 (*acur)[MB] = (j & 1) ? a1 : a0;
+          uint4 (*anxt)[MB] = (j & 1) ? a0 : a1;
+          const int noff = (j + 1 < NJ) ? tapoff + (j + 1) * 16 : ntapoff;
+#pragma unroll
+          for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) anxt[s][mb] = *reinterpret_cast<const uint4*>(tile + s * PL + abase[mb] + noff);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, bq[j][0]);
+          const bf16x8_t b2 = __builtin_bit_cast(bf16x8_t, bq[j][1]);
+          const bf16x8_t b3 = __builtin_bit_cast(bf16x8_t, bq[j][2]);
+          // smallest terms first; the blocks alternate so that consecutive MFMAs are independent
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[2][mb]), b1, acc[mb], 0, 0, 0);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[0][mb]), b3, acc[mb], 0, 0, 0);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[1][mb]), b2, acc[mb], 0, 0, 0);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[1][mb]), b1, acc[mb], 0, 0, 0);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[0][mb]), b2, acc[mb], 0, 0, 0);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[0][mb]), b1, acc[mb], 0, 0, 0);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) bq[j][s] = *reinterpret_cast<const uint4*>(wnext + s * split_off + j * jstride);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        tx = ntx; ty = nty;
+        if constexpr (KIND == 4) if ((tap & 3) == 3) {
+          // one output parity is complete: registers -> HBM (the input tile stays in LDS for the next parity)
+          par = tap >> 2; py = par >> 1; px = par & 1;
+          conv_epilogue<MB, 4>(p, acc, reinterpret_cast<float*>(tile + 3 * PL), nullptr, par, py, px, img0, tin, y0, x0,
+                               wm, wn, lane, h, tid, wave, bias_lane, true);
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+        }
+      }
+    }
+    DM_TL(3);
+    if constexpr (KIND != 4) {
+      __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
+      __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
+      conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, 0, 0, 0, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, bias_lane, true);
+    }
+    __syncthreads();  // output staging / reduction words are free again for the next tile
+    DM_TL(4);
+  }
+}
+
+// Three-way bf16 split of a conv weight in B-fragment order (see conv_x6_kernel):
+//   out[s][par][tap][cin/16][cout/32][lane][8],  s = 0, 1, 2:  w = out[0] + out[1] + out[2] to 2^-27 |w|
+__global__ void pack_conv_weight_x6_kernel(int kind, const float* __restrict__ w, int cin, int cout,
+                                           bf16_t* __restrict__ out, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int nty = kind == 0 ? 3 : kind == 1 ? 4 : 2;
+  const int nt = nty * nty;
+  const int ks = kind == 0 ? 3 : 4;
+  size_t r = idx;
+  const int e = r & 7; r >>= 3;
+  const int lane = r & 63; r >>= 6;
+  const int nb = r % (cout >> 5); r /= (cout >> 5);
+  const int c16 = r % (cin >> 4); r /= (cin >> 4);
+  const int tap = r % nt; r /= nt;
+  const int par = (int)r;
+  const int ty = tap / nty, tx = tap % nty;
+  int ky = ty, kx = tx;
+  if (kind == 2) { ky = 3 - (par >> 1) - 2 * ty; kx = 3 - (par & 1) - 2 * tx; }
+  const int co = nb * 32 + (lane & 31);
+  const int ci = c16 * 16 + 8 * (lane >> 5) + e;
+  const size_t src = (kind == 2) ? (((size_t)ci * cout + co) * ks + ky) * ks + kx
+                                 : (((size_t)co * cin + ci) * ks + ky) * ks + kx;
+  float wv = w[src];
+  const bf16_t s1 = f2bf(wv);
+  wv -= bf2f(s1);
+  const bf16_t s2 = f2bf(wv);
+  wv -= bf2f(s2);
+  out[idx] = s1;
+  out[total + idx] = s2;
+  out[2 * total + idx] = f2bf(wv);
+}
