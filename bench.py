@@ -44,10 +44,12 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 K_NAMES = ["init_conv", "conv3x3_mfma_t128", "conv3x3_mfma_t64", "conv4x4s2_mfma", "convT4x4s2_mfma_t128",
-           "convT4x4s2_mfma_t64", "final_conv", "time_embed", "sampler_step", "attention", "conv3x3_winograd_mfma"]
+           "convT4x4s2_mfma_t64", "final_conv", "time_embed", "sampler_step", "attention", "conv3x3_winograd_mfma",
+           "conv3x3_bf16x6_mfma", "conv4x4s2_bf16x6_mfma", "convT4x4s2_bf16x6_mfma"]
 NK = len(K_NAMES)  # DM_K_COUNT
 K_WINO = 10
-MFMA_CLASSES = (1, 2, 3, 4, 5, 9, 10)
+MFMA_CLASSES = (1, 2, 3, 4, 5, 9, 10, 11, 12, 13)
+X6_CLASSES = (11, 12, 13)  # fp32 convolutions on the bf16 pipe: six bf16 MFMAs per fp32 product (three-way split operands)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_traffic.json")  # PMC passes of this round's build (profiles/README.md)
 
 
@@ -83,7 +85,10 @@ def profile_model(model, sched, B, H, W, reps=3):
             tf = fl[k] / (ms[k] * 1e-3) / 1e12
             e = {"launches": counts[k] // reps, "avg_us": 1e3 * ms[k] / counts[k], "share": ms[k] / tot_ms, "tflops": tf,
                  "alg_gbps": by[k] / (ms[k] * 1e-3) / 1e9}
-            if k in MFMA_CLASSES:  # executed MFMA fraction (the Winograd class executes 4/9 of its algorithmic FLOPs)
+            if k in X6_CLASSES and not bf16:  # executed bf16 MFMA FLOPs = 6 x the algorithmic fp32 FLOPs, priced on the bf16 peak
+                e["executed_mfma_frac"] = tf * 6.0 / PEAK_BF16_MFMA_TFLOPS
+                e["pipe"] = "bf16 MFMA, three-way split operands (fp32-equivalent accuracy)"
+            elif k in MFMA_CLASSES:  # executed MFMA fraction (the Winograd class executes 4/9 of its algorithmic FLOPs)
                 e["executed_mfma_frac"] = tf * (4.0 / 9.0 if k == K_WINO else 1.0) / peak
             per[K_NAMES[k]] = e
     raw = {"counts": counts, "ms": ms, "fl": fl, "by": by, "tot_ms": tot_ms}

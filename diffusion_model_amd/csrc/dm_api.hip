@@ -124,7 +124,7 @@ unsigned long long* g_stamps = nullptr;  // diagnostic build: set through dm_deb
 #endif
 
 #ifndef DM_X6_DEFAULT
-#define DM_X6_DEFAULT 3
+#define DM_X6_DEFAULT 7
 #endif
 struct ConvCall {
   int kind;
@@ -188,23 +188,23 @@ int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
   return 0;
 }
 
-template <int MB, int KIND>
+template <int MB, int KIND, bool SW>
 int launch_conv_x6_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_done[DM_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MB, KIND>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MB, KIND, SW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
   constexpr bool UP = (KIND == 4);
-  const int cls = KIND == 0 ? (MB == 2 ? DM_K_CONV3_128 : DM_K_CONV3_64) : KIND == 1 ? DM_K_DOWN : (MB == 2 ? DM_K_UP_128 : DM_K_UP_64);
+  const int cls = KIND == 0 ? DM_K_X6_CONV3 : KIND == 1 ? DM_K_X6_DOWN : DM_K_X6_UP;
   const double opix = (double)a.B * a.Hb * a.Wb * (UP ? 4 : 1);
   const double ipix = (double)a.B * a.H * a.W;
   const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : 4;
   const int cin = a.C1 + a.C2;
   ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 4.0 * (ipix * cin + opix * a.Cout) + 6.0 * taps * (UP ? 4 : 1) * cin * a.Cout);
-  hipLaunchKernelGGL((conv_x6_kernel<MB, KIND>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_x6_kernel<MB, KIND, SW>), grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -251,7 +251,7 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   const size_t np = (size_t)g.ni * g.hth * g.htw;
   if (np * 8 > 6 * 256 * 4) return fail("conv (split-bf16): tile of %zu halo pixels is too large", np);
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
-  size_t lds_f = (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (3 * np * 72 + 1) / 2 + (kind == 2 ? 128 : 0);
+  size_t lds_f = (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (3 * np * 72 + 1) / 2 + 128;  // + reduction words behind the planes
   if (lds_f < epi_f) lds_f = epi_f;
   const size_t lds = lds_f * sizeof(float);
   if (lds > 160 * 1024) return fail("conv (split-bf16): tile needs %zu B of LDS (> 160 KiB)", lds);
@@ -270,9 +270,13 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
 #ifdef DM_STAMPS
   a.stamps = g_stamps;
 #endif
-  if (kind == 0) return g.MT == 128 ? launch_conv_x6_t<2, 0>(a, grid, lds, s) : launch_conv_x6_t<1, 0>(a, grid, lds, s);
-  if (kind == 1) return g.MT == 128 ? launch_conv_x6_t<2, 1>(a, grid, lds, s) : launch_conv_x6_t<1, 1>(a, grid, lds, s);
-  return g.MT == 128 ? launch_conv_x6_t<2, 4>(a, grid, lds, s) : launch_conv_x6_t<1, 4>(a, grid, lds, s);
+  // one image per tile: swapped MFMA operands, stores straight from the registers (x6_epilogue_sw)
+  const bool sw = g.ni == 1 && getenv("DM_DEBUG_NOSWAP") == nullptr;
+#define DM_X6(MB_, K_) (sw ? launch_conv_x6_t<MB_, K_, true>(a, grid, lds, s) : launch_conv_x6_t<MB_, K_, false>(a, grid, lds, s))
+  if (kind == 0) return g.MT == 128 ? DM_X6(2, 0) : DM_X6(1, 0);
+  if (kind == 1) return g.MT == 128 ? DM_X6(2, 1) : DM_X6(1, 1);
+  return g.MT == 128 ? DM_X6(2, 4) : DM_X6(1, 4);
+#undef DM_X6
 }
 
 int launch_conv(const ConvCall& c, hipStream_t s) {
@@ -687,7 +691,8 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   // Block.forward (model.py:52-64); in: block input(s) at hxw
   // 3x3 convolutions: Winograd F(2x2,3x3) in fp32 from 8x8 up, the direct form below that and in bf16
   // (split-bf16 form, conv_x6_kernel: where m->x6 selects it)
-  auto x3 = [&](int h, int ww) { return (x6 & 8) || ((x6 & 4) && (h < 8 || ww < 8)); };
+  // (not below 16 pixels per image: 16-64 single-pixel images with their halos do not fit the CU's LDS as three planes)
+  auto x3 = [&](int h, int ww) { return h * ww >= 16 && ((x6 & 8) || ((x6 & 4) && (h < 8 || ww < 8))); };
   auto k3 = [&](int h, int ww) { return (!m->bf16 && !x3(h, ww) && h >= 8 && ww >= 8) ? 5 : 0; };
   auto block = [&](int k, const float* in1, const float* in2, int h, int ww, bool up, float* out, float* out_stats) -> int {
     const BlockOff& o = m->blk[k];
@@ -706,7 +711,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     c.step_ptr = step_ptr; c.step_off = step_off;
     if (launch_conv(c, s)) return 1;
     const int kdn = (!m->bf16 && (h / 2) * (ww / 2) >= 256) ? 6 : 1;  // stride-2 conv: 128-pixel tiles from 16x16 outputs up
-    const bool xt = up ? ((x6 & 2) && h * ww >= 16 && C == 64) : (x6 & 1) != 0;  // (transposed: single K chunk only)
+    const bool xt = up ? ((x6 & 2) && h * ww >= 16 && C == 64) : ((x6 & 1) && (h / 2) * (ww / 2) >= 16);  // (transposed: single K chunk only)
     base(up ? 2 : kdn, w.T2, C, nullptr, 0, xt ? o.trx : o.tr, o.trb, out, out_stats, h, ww);
     c.x6 = xt;
     with_tf(w.SB, kd, h, ww, o.g2, o.b2);

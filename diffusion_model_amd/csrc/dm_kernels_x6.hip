@@ -35,7 +35,94 @@ __device__ __forceinline__ void dm_split3(float a, float b, unsigned& s1, unsign
   s3 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, dm_bf2));
 }
 
+// Epilogue for the SWAPPED accumulator layout (weights as the MFMA's A operand, pixels as B): lane l holds pixel
+// (l & 31) of its 32-pixel block and the 16 channels  wn*32 + 8k + 4(l >> 5) + e  (k = r >> 2, e = r & 3), i.e. four
+// runs of four consecutive channels -> + bias, GroupNorm (mean, M2) partials, and 16-byte NHWC stores straight from the
+// registers: no LDS staging, no per-element address math.  One image per tile (ni == 1).  scr: 64 floats of LDS.
 template <int MB, int KIND>
+__device__ __forceinline__ void x6_epilogue_sw(const ConvArgs& p, f32x16 (&acc)[MB], float* scr, int par, int py, int px,
+                                               int img0, int tin, int y0, int x0, int wm, int wn, int lane, int h, int tid, int wave) {
+  constexpr bool UP = (KIND == 4);
+  constexpr int MT = 64 * MB;
+  const int OW = (KIND == 1) ? (p.W >> 1) : UP ? (p.W << 1) : p.W;
+  const int OH = (KIND == 1) ? (p.H >> 1) : UP ? (p.H << 1) : p.H;
+  const int cb = blockIdx.y * 64 + wn * 32 + 4 * h;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + cb + 8 * k);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      acc[mb][4 * k] += bv.x; acc[mb][4 * k + 1] += bv.y; acc[mb][4 * k + 2] += bv.z; acc[mb][4 * k + 3] += bv.w;
+    }
+  }
+  if (p.stats_out) {
+    // channels per group G = 8 .. 64; this wave's 32 channels hold 32/G groups (G = 64: half a group)
+    const int kg_log = p.g_log - 3 < 2 ? p.g_log - 3 : 2;  // log2(k runs per group inside the wave): 0, 1, 2
+    const int ngw = 4 >> kg_log;                           // group slots of this wave
+    const int gpt_log = 6 - p.g_log, gpt = 1 << gpt_log;   // groups in the workgroup's 64 channels
+    float* sredA = scr;        // [4 waves][4]
+    float* sredB = scr + 16;   // [4 waves][4]
+    float* s_mu = scr + 32;    // [<= 8]
+    const float inv_cnt = 1.0f / (float)(MT << p.g_log);
+    for (int pass = 0; pass < 2; ++pass) {
+      float val[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float mu = pass ? s_mu[(wn * 4 + k) >> (p.g_log - 3)] : 0.f;
+        float sm = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = acc[mb][4 * k + e] - mu;
+            sm += pass ? d * d : d;
+          }
+        val[k] = sm;
+      }
+      if (kg_log >= 1) { val[0] += val[1]; val[2] += val[3]; val[1] = val[2]; }
+      if (kg_log == 2) val[0] += val[1];
+      float* sred = pass ? sredB : sredA;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < ngw) {
+          float v = val[q];
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+          if (lane == 0) sred[wave * 4 + q] = v;
+        }
+      }
+      __syncthreads();
+      if (tid < gpt) {
+        // waves (wm, wn) and slot that hold group tid of this 64-channel tile
+        float sm;
+        if (p.g_log == 6) sm = (sred[0] + sred[4]) + (sred[8] + sred[12]);
+        else {
+          const int c0 = tid << p.g_log, wn0 = c0 >> 5, q = (c0 & 31) >> p.g_log;
+          sm = sred[wn0 * 4 + q] + sred[(2 + wn0) * 4 + q];
+        }
+        if (pass == 0) s_mu[tid] = sm * inv_cnt;
+        else {
+          const int pidx = (UP ? par * p.tiles_per_img : 0) + tin;
+          float* so = p.stats_out + (((size_t)img0 * p.pout + pidx) * DM_GROUPS + blockIdx.y * gpt + tid) * 2;
+          so[0] = s_mu[tid];
+          so[1] = sm;
+        }
+      }
+      if (pass == 0) __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = wm * (32 * MB) + mb * 32 + (lane & 31);
+    const int x = x0 + (m & ((1 << p.tw_log) - 1)), y = y0 + (m >> p.tw_log);
+    const int oy = UP ? 2 * y + py : y, ox = UP ? 2 * x + px : x;
+    float* q = p.y + ((((size_t)img0 * OH + oy) * OW + ox) << p.cout_log) + cb;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      *reinterpret_cast<float4*>(q + 8 * k) = make_float4(acc[mb][4 * k], acc[mb][4 * k + 1], acc[mb][4 * k + 2], acc[mb][4 * k + 3]);
+  }
+}
+
+template <int MB, int KIND, bool SW = false>
 __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   constexpr int KC = 64;
   constexpr int MT = 64 * MB;
@@ -63,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   const int NP = p.ni * hth * htw;
   const int items = NP * 8;
   const int step_now = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
-  const float bias_lane = p.bias[blockIdx.y * 64 + wn * 32 + (lane & 31)];
+  const float bias_lane = SW ? 0.f : p.bias[blockIdx.y * 64 + wn * 32 + (lane & 31)];
 
   const bool tf = p.stats_in != nullptr;
   float* s_scale = smem;
@@ -126,8 +213,10 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
       const float* src = from2 ? p.x2 : p.x1;
       const int cs_log = from2 ? p.c2_log : p.c1_log;
       const int coff = from2 ? cg0 - p.C1 : cg0;
+      // wave-uniform weight pointer (scalar registers) + one 32-bit lane byte offset: saddr-form loads, no 64-bit vector adds
       const int wn_s = __builtin_amdgcn_readfirstlane(wn);
-      const bf16_t* wbase = wpk + (size_t)cch * NJ * jstride + (size_t)(blockIdx.y * 2 + wn_s) * 512 + lane * 8;
+      const bf16_t* wbase = wpk + (size_t)cch * NJ * jstride + (size_t)(blockIdx.y * 2 + wn_s) * 512;
+      const unsigned lane16 = (unsigned)lane * 16u;
       if (chunk > 0) {
         DM_TL(5);
         __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
@@ -222,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int s = 0; s < 3; ++s) bq[j][s] = *reinterpret_cast<const uint4*>(w0 + s * split_off + j * jstride);
+          for (int s = 0; s < 3; ++s) bq[j][s] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w0 + s * split_off + j * jstride) + lane16);
       }
       __syncthreads();
       __builtin_amdgcn_s_setprio(DM_PRIO_K);
@@ -234,10 +323,14 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
           for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
       }
       uint4 a0[3][MB], a1[3][MB];
+      const bf16_t* ap[3][MB];  // this lane's fragment address per plane at tap (0,0): per step only (tap offset) + immediate
 #pragma unroll
       for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) a0[s][mb] = *reinterpret_cast<const uint4*>(tile + s * PL + abase[mb]);
+        for (int mb = 0; mb < MB; ++mb) {
+          ap[s][mb] = tile + s * PL + abase[mb];
+          a0[s][mb] = *reinterpret_cast<const uint4*>(ap[s][mb]);
+        }
       int ty = 0, tx = 0;
 #pragma unroll 1
       for (int tap = 0; tap < NTOT; ++tap) {
@@ -257,37 +350,38 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
           uint4 (*acur)[MB] = (j & 1) ? a1 : a0;
           uint4 (*anxt)[MB] = (j & 1) ? a0 : a1;
           const int noff = (j + 1 < NJ) ? tapoff + (j + 1) * 16 : ntapoff;
-#pragma unroll
-          for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) anxt[s][mb] = *reinterpret_cast<const uint4*>(tile + s * PL + abase[mb] + noff);
-          __builtin_amdgcn_sched_barrier(0);
+          // One memory instruction behind each MFMA: a batch of nine (six LDS reads, three weight loads) takes ~170
+          // cycles to issue, during which this wave feeds the matrix pipe nothing; one at a time they issue while
+          // the MFMA in front of them executes (32 cycles).  Products in the order a1b3, a2b2, a1b2, a3b1, a2b1, a1b1
+          // (small terms first); a weight term is reloaded for the next tap right after its last use.
           const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, bq[j][0]);
           const bf16x8_t b2 = __builtin_bit_cast(bf16x8_t, bq[j][1]);
           const bf16x8_t b3 = __builtin_bit_cast(bf16x8_t, bq[j][2]);
-          // smallest terms first; the blocks alternate so that consecutive MFMAs are independent
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[2][mb]), b1, acc[mb], 0, 0, 0);
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[0][mb]), b3, acc[mb], 0, 0, 0);
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[1][mb]), b2, acc[mb], 0, 0, 0);
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[1][mb]), b1, acc[mb], 0, 0, 0);
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[0][mb]), b2, acc[mb], 0, 0, 0);
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, acur[0][mb]), b1, acc[mb], 0, 0, 0);
-#pragma unroll
-          for (int s = 0; s < 3; ++s) bq[j][s] = *reinterpret_cast<const uint4*>(wnext + s * split_off + j * jstride);
           __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 6; ++t) {
+            const int as = (t == 1 || t == 4) ? 1 : (t == 3) ? 2 : 0;
+            const bf16x8_t bv = (t == 0) ? b3 : (t == 1 || t == 2) ? b2 : b1;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+              const bf16x8_t av = __builtin_bit_cast(bf16x8_t, acur[as][mb]);
+              acc[mb] = SW ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[mb], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mb], 0, 0, 0);
+              if (t < 3) anxt[t][mb] = *reinterpret_cast<const uint4*>(ap[t][mb] + noff);
+              if (t == 3 && mb == 0) bq[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * split_off + j * jstride) + lane16);
+              if (t == 4 && mb == 0) bq[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + split_off + j * jstride) + lane16);
+              if (t == 5 && mb == MB - 1) bq[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + j * jstride) + lane16);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
         }
         tx = ntx; ty = nty;
         if constexpr (KIND == 4) if ((tap & 3) == 3) {
           // one output parity is complete: registers -> HBM (the input tile stays in LDS for the next parity)
           par = tap >> 2; py = par >> 1; px = par & 1;
-          conv_epilogue<MB, 4>(p, acc, reinterpret_cast<float*>(tile + 3 * PL), nullptr, par, py, px, img0, tin, y0, x0,
-                               wm, wn, lane, h, tid, wave, bias_lane, true);
+          if constexpr (SW) x6_epilogue_sw<MB, 4>(p, acc, reinterpret_cast<float*>(tile + 3 * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
+          else conv_epilogue<MB, 4>(p, acc, reinterpret_cast<float*>(tile + 3 * PL), nullptr, par, py, px, img0, tin, y0, x0,
+                                    wm, wn, lane, h, tid, wave, bias_lane, true);
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -298,8 +392,12 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
     DM_TL(3);
     if constexpr (KIND != 4) {
       __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
-      __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
-      conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, 0, 0, 0, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, bias_lane, true);
+      if constexpr (SW) {  // registers -> HBM; the reduction words sit behind the planes (no overlay, no barrier)
+        x6_epilogue_sw<MB, KIND>(p, acc, reinterpret_cast<float*>(tile + 3 * PL), 0, 0, 0, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
+      } else {
+        __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
+        conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, 0, 0, 0, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, bias_lane, true);
+      }
     }
     __syncthreads();  // output staging / reduction words are free again for the next tile
     DM_TL(4);

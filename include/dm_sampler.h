@@ -180,7 +180,10 @@ enum {
   DM_K_STEP = 8,      /* sampler_step_kernel                                (HBM-bound) */
   DM_K_ATTN = 9,      /* attention block: 1x1 qkv/proj convs, QK^T / PV GEMMs, softmax  */
   DM_K_WINO = 10,     /* conv_mfma_kernel<2,5,64>: 3x3 convs as Winograd F(2x2,3x3)  (MFMA) */
-  DM_K_COUNT = 11
+  DM_K_X6_CONV3 = 11, /* conv_x6_kernel<.,0>: 3x3 convs on the bf16 pipe, 3-way split operands (6 MFMAs per fp32 product) */
+  DM_K_X6_DOWN = 12,  /* conv_x6_kernel<.,1>: 4x4 stride-2 convs, same arithmetic                   */
+  DM_K_X6_UP = 13,    /* conv_x6_kernel<.,4>: transposed 4x4 s2 convs, same arithmetic              */
+  DM_K_COUNT = 14
 };
 int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int64_t* t_dev,
                     const float* coef_host, int B, int H, int W, void* workspace_dev,

@@ -1,0 +1,136 @@
+"""Per-kernel parity (GPU) of the split-bf16 convolutions (conv_x6_kernel: fp32 operands as three bf16 terms, six bf16
+MFMAs per product, fp32 accumulation) through the C ABI against stock torch-CPU fp32 ops — to the SAME bounds as the
+fp32-MFMA kernels (tests/test_gpu_kernels.py): the arithmetic is fp32-equivalent, not a reduced-precision mode.
+kinds 7 / 8 / 9 = Conv2d 3x3 (model.py:41,45), Conv2d 4x4 stride 2 (model.py:46), ConvTranspose2d 4x4 stride 2 (model.py:43)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from diffusion_model_amd import _lib
+from tests.test_gpu_kernels import DEV, merge_stats, nchw, nhwc, stream
+
+pytestmark = pytest.mark.gpu
+
+
+def run_x6(kind, x1, x2, w, b, tf=None, want_stats=True):
+    L = _lib.lib()
+    B, c1, H, W = x1.shape
+    c2 = 0 if x2 is None else x2.shape[1]
+    cin = c1 + c2
+    cout = w.shape[1] if kind == 9 else w.shape[0]
+    OH, OW = (H, W) if kind == 7 else (H // 2, W // 2) if kind == 8 else (2 * H, 2 * W)
+    wp = torch.empty(L.dm_conv_packed_floats(kind, cin, cout), device=DEV)
+    wd = w.to(DEV).contiguous()
+    _lib.check(L.dm_pack_conv_weight(kind, _lib.ptr(wd), cin, cout, _lib.ptr(wp), stream()))
+    a1 = nhwc(x1).to(DEV)
+    a2 = None if x2 is None else nhwc(x2).to(DEV)
+    bd = b.to(DEV)
+    y = torch.full((B, OH, OW, cout), float("nan"), device=DEV)
+    pout = L.dm_conv_stats_partials(kind, H, W)
+    so = torch.full((B, pout, 8, 2), float("nan"), device=DEV) if want_stats else None
+    si = g = be = te = None
+    pin, cnt, ts = 0, 0.0, 0
+    if tf is not None:
+        si, pin, cnt, g, be, te, ts = tf
+    _lib.check(L.dm_conv2d(kind, _lib.ptr(a1), c1, _lib.ptr(a2), c2, _lib.ptr(wp), _lib.ptr(bd), cout,
+                           _lib.ptr(si), pin, cnt, _lib.ptr(g), _lib.ptr(be), _lib.ptr(te), ts,
+                           _lib.ptr(y), _lib.ptr(so), B, H, W, stream()))
+    torch.cuda.synchronize()
+    return nchw(y.cpu()), (None if so is None else so.cpu())
+
+
+def ref_conv(kind, x, w, b):
+    return (F.conv2d(x, w, b, padding=1) if kind == 7 else F.conv2d(x, w, b, stride=2, padding=1) if kind == 8
+            else F.conv_transpose2d(x, w, b, stride=2, padding=1))
+
+
+def check_stats(st, ref, B):
+    P = st.shape[1]
+    cout = ref.shape[1]
+    cnt = ref.shape[2] * ref.shape[3] * (cout // 8) / P
+    mean, var = merge_stats(st, cnt)
+    rg = ref.reshape(B, 8, -1)
+    assert (mean - rg.mean(2)).abs().max().item() <= 1e-5
+    assert ((var - rg.var(2, unbiased=False)).abs() / rg.var(2, unbiased=False)).max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("kind", [7, 8, 9])
+@pytest.mark.parametrize("B,H", [(3, 32), (2, 16), (5, 8), (9, 4), (1, 4), (130, 16)])
+def test_x6_conv_plain(kind, B, H):
+    """Every tile shape of the model's levels (128- and 64-pixel tiles, several images per tile, ragged last tile)."""
+    if kind == 8 and H < 8:
+        H = 8
+    torch.manual_seed(kind * 100 + B + H)
+    x = torch.randn(B, 64, H, H) * 3.0 + 0.5
+    w = torch.randn(64, 64, 3 if kind == 7 else 4, 3 if kind == 7 else 4) * 0.05
+    b = torch.randn(64)
+    y, st = run_x6(kind, x, None, w, b)
+    ref = ref_conv(kind, x, w, b)
+    assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    check_stats(st, ref, B)
+
+
+@pytest.mark.parametrize("kind,B,H,cin,cout", [(7, 2, 16, 128, 64), (7, 2, 64, 256, 256), (8, 2, 64, 256, 256), (7, 3, 8, 512, 128),
+                                               (8, 2, 16, 128, 256), (7, 3, 4, 128, 64)])
+def test_x6_conv_wide_and_concat(kind, B, H, cin, cout):
+    """Several K chunks, several 64-channel output tiles, GroupNorm groups of 8..32 channels; the two-pointer
+    channel concat (model.py:146-148) when cin = 2 * 64."""
+    torch.manual_seed(kind + B + H + cin)
+    x = torch.randn(B, cin, H, H)
+    k = 3 if kind == 7 else 4
+    w = torch.randn(cout, cin, k, k) * (1.0 / (k * cin ** 0.5))
+    b = torch.randn(cout)
+    if cin == 128 and kind == 7:
+        y, st = run_x6(kind, x[:, :64].contiguous(), x[:, 64:].contiguous(), w, b)
+    else:
+        y, st = run_x6(kind, x, None, w, b)
+    ref = ref_conv(kind, x, w, b)
+    assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    check_stats(st, ref, B)
+
+
+@pytest.mark.parametrize("kind,H", [(7, 32), (8, 32), (9, 16), (8, 16), (9, 8), (7, 4)])
+def test_x6_conv_fused_groupnorm_silu_temb(kind, H):
+    """Input transform SiLU(GroupNorm8(x)) + temb applied while staging (model.py:54-62), from producer partials."""
+    torch.manual_seed(kind + H)
+    B = 3
+    h_raw = torch.randn(B, 64, H, H) * 2.0 + 1.5
+    # producer partials: one (mean, M2) per image and group over the whole image (pin = 1)
+    hg = h_raw.reshape(B, 8, -1)
+    mean = hg.mean(2)
+    st0 = torch.stack([mean, ((hg - mean[:, :, None]) ** 2).sum(2)], dim=-1).reshape(B, 1, 8, 2)
+    gamma, beta, temb = torch.rand(64) + 0.5, torch.randn(64) * 0.1, torch.randn(1, 64)
+    tf = (st0.to(DEV), 1, float(H * H * 8), gamma.to(DEV), beta.to(DEV), temb.to(DEV), 0)
+    k = 3 if kind == 7 else 4
+    w, b = torch.randn(64, 64, k, k) * 0.05, torch.randn(64)
+    y, st = run_x6(kind, h_raw, None, w, b, tf=tf)
+    hin = F.silu(F.group_norm(h_raw, 8, gamma, beta, eps=1e-5)) + temb[:, :, None, None]
+    ref = ref_conv(kind, hin, w, b)
+    assert (y - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+    check_stats(st, ref, B)
+
+
+def test_x6_split_keeps_fp32_accuracy_on_badly_scaled_inputs():
+    """Operands spanning many binades (1e-6 .. 1e4): the three-term split carries 24 mantissa bits whatever the
+    magnitude, so the result stays within fp32 rounding of the float64 convolution, relative to sum |x||w|."""
+    torch.manual_seed(5)
+    B, H = 2, 16
+    x = torch.randn(B, 64, H, H) * torch.exp(torch.randn(B, 64, H, H) * 4.0)
+    w = torch.randn(64, 64, 3, 3) * 0.05 * torch.exp(torch.randn(64, 64, 3, 3) * 2.0)
+    b = torch.zeros(64)
+    y, _ = run_x6(7, x, None, w, b, want_stats=False)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    scale = F.conv2d(x.abs().double(), w.abs().double(), None, padding=1)
+    assert ((y.double() - ref).abs() / scale).max().item() <= 2e-6
+
+
+def test_x6_rows_of_a_large_batch_match_a_small_batch():
+    """Persistent workgroups walk many tiles (XCD-aware order): rows of a B=600 launch == the same rows alone, bit for bit."""
+    torch.manual_seed(9)
+    for kind, H in ((7, 16), (8, 32), (9, 16)):
+        k = 3 if kind == 7 else 4
+        x = torch.randn(600, 64, H, H)
+        w, b = torch.randn(64, 64, k, k) * 0.05, torch.randn(64)
+        y, st = run_x6(kind, x, None, w, b)
+        y2, st2 = run_x6(kind, x[592:].contiguous(), None, w, b)
+        assert torch.equal(y[592:], y2) and torch.equal(st[592:], st2)

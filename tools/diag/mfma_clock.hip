@@ -9,7 +9,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
-template <int V>  // 0: fp32 32x32x2, 1: bf16 32x32x16 random O(1) operands, 2: bf16 with zero operands
+template <int V, int NACC = 4>  // 0: fp32 32x32x2, 1: bf16 32x32x16; NACC independent accumulators (dependency distance)
 __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ src, float* out, int iters, unsigned long long* clk) {
   const int tid = threadIdx.x;
   f32x16 acc[4];
@@ -19,9 +19,9 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ src, float
   unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int e = 0; e < 32 / NACC; ++e)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NACC; ++q) {
         if (V == 0) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[q], 0, 0, 0);
         else acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ua), __builtin_bit_cast(bf16x8, ub), acc[q], 0, 0, 0);
       }
@@ -32,11 +32,11 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ src, float
   out[blockIdx.x * 256 + tid] = s;
   if (tid == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
 }
-template <int V> void run(const char* name, const float* src, float* out, unsigned long long* clk, int blocks, int iters, double flop_per_mfma) {
+template <int V, int NACC = 4> void run(const char* name, const float* src, float* out, unsigned long long* clk, int blocks, int iters, double flop_per_mfma) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k<V>), dim3(blocks), dim3(256), 0, 0, src, out, iters, clk);
+    hipLaunchKernelGGL((k<V, NACC>), dim3(blocks), dim3(256), 0, 0, src, out, iters, clk);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
   }
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -60,6 +60,11 @@ int main() {
   run<0>("fp32 32x32x2, random operands, 2 waves/SIMD", src, out, clk, 512, iters / 2, 4096.0);
   run<1>("bf16 32x32x16, random operands, 1 wave/SIMD", src, out, clk, 256, iters, 32768.0);
   run<1>("bf16 32x32x16, random operands, 2 waves/SIMD", src, out, clk, 512, iters, 32768.0);
+  run<1, 2>("bf16 32x32x16, 2 accumulators (distance 2), 1 wave/SIMD", src, out, clk, 256, iters, 32768.0);
+  run<1, 1>("bf16 32x32x16, 1 accumulator (distance 1), 1 wave/SIMD", src, out, clk, 256, iters, 32768.0);
+  run<1, 3>("bf16 32x32x16, 3 accumulators, 1 wave/SIMD", src, out, clk, 256, iters, 32768.0 * 30 / 32);
+  run<0, 2>("fp32 32x32x2, 2 accumulators, 1 wave/SIMD", src, out, clk, 256, iters / 2, 4096.0);
+  run<0, 1>("fp32 32x32x2, 1 accumulator, 1 wave/SIMD", src, out, clk, 256, iters / 2, 4096.0);
   CK(hipMemset(src, 0, 1 << 20));
   run<1>("bf16 32x32x16, zero operands, 2 waves/SIMD", src, out, clk, 512, iters, 32768.0);
   run<0>("fp32 32x32x2, zero operands, 2 waves/SIMD", src, out, clk, 512, iters / 2, 4096.0);
