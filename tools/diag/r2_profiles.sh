@@ -21,6 +21,9 @@ traffic)
 sq)
   # one Winograd 32x32 layer (B=1024) launched 6x, and the fused attention kernel (B=256, T=256, C=256)
   timeout -s KILL 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_wino -- python3 $R/tools/diag/pmc_layer.py 5 32 1024 > $O/pmc_sq_wino.log 2>&1 || exit 1
+  # the split-bf16 stride-2 (32x32 -> 16x16) and transposed (16x16 -> 32x32) layers, B=1024
+  timeout -s KILL 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_x6down -- python3 $R/tools/diag/pmc_layer.py 8 32 1024 > $O/pmc_sq_x6down.log 2>&1 || exit 1
+  timeout -s KILL 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_x6up -- python3 $R/tools/diag/pmc_layer.py 9 16 1024 > $O/pmc_sq_x6up.log 2>&1 || exit 1
   timeout -s KILL 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_attn -- python3 $R/tools/diag/pmc_attention.py > $O/pmc_sq_attn.log 2>&1 || exit 1
   ;;
 esac
