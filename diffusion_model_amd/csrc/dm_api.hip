@@ -249,7 +249,7 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   a.g1_log = ilog2(c.c1 / DM_GROUPS);
   (void)cin;
   const size_t np = (size_t)g.ni * g.hth * g.htw;
-  if (np * 8 > 6 * 256 * 4) return fail("conv (split-bf16): tile of %zu halo pixels is too large", np);
+  if (np * 8 > 3 * 256 * 8) return fail("conv (split-bf16): tile of %zu halo pixels is too large", np);
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
   size_t lds_f = (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (3 * np * 72 + 1) / 2 + 128;  // + reduction words behind the planes
   if (lds_f < epi_f) lds_f = epi_f;
@@ -260,7 +260,7 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   a.ntiles = (int)grid.x;
   {
     static const unsigned slot_div = getenv("DM_DEBUG_SLOT_DIV") ? (unsigned)atoi(getenv("DM_DEBUG_SLOT_DIV")) : 1u;  // diagnostics only
-    const unsigned per_cu = lds > 80 * 1024 ? 1u : 2u;
+    const unsigned per_cu = lds > 80 * 1024 ? 1u : (lds <= 53 * 1024 && g.MT == 64 && getenv("DM_DEBUG_X6_2WG") == nullptr) ? 3u : 2u;  // (64-pixel tiles: <= 159 registers)
     const unsigned slots = per_cu * cu_count(current_device()) / (slot_div ? slot_div : 1u);
     const unsigned resident = slots / grid.y ? slots / grid.y : 1u;
     if (grid.x > resident) grid.x = resident;

@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   constexpr int NTW = (KIND == 0) ? 9 : (KIND == 1) ? 16 : 4;  // taps per parity in the packed weights
   constexpr int NTOT = (KIND == 4) ? 16 : NT;
   constexpr int NJ = KC / 16;
-  constexpr int U = 6;          // staging items (8 channels = two 16-byte loads) per thread and batch
+  // staging items (8 channels = two 16-byte loads) per thread and batch: one batch covers the model's tiles without an
+  // idle slot (KIND 1: 17x9 / 9x9 phase planes = 1224 / 648 items; 3x3 and transposed: 10x18 = 1440, 10x10 = 800, 4 x 6x6 = 1152)
+  constexpr int U = (KIND == 1) ? (MB == 2 ? 5 : 3) : (MB == 2 ? 6 : 5);
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);

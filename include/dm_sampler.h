@@ -196,7 +196,10 @@ int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int
  * attention block), 5 = the same Conv2d 3x3 pad 1 as kind 0 evaluated as Winograd F(2x2,3x3) in fp32
  * (H, W >= 8; what dm_unet_forward uses for its 3x3 layers from 8x8 up), 6 = the Conv2d 4x4 stride 2
  * of kind 1 on 128-pixel tiles with 16-channel K chunks (fp32, outputs of >= 128 pixels; same packed
- * weights as kind 1; what dm_unet_forward uses from 16x16 outputs up). */
+ * weights as kind 1), 7 / 8 / 9 = kinds 0 / 1 / 2 computed on the bf16 matrix pipe with fp32-equivalent accuracy:
+ * every fp32 operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation
+ * (conv_x6_kernel; own packed-weight format, 1.5 floats per weight; what dm_unet_forward uses for its
+ * stride-2 and transposed convolutions and for the 3x3 convolutions at 4x4 pixels: DM_X6). */
 size_t dm_conv_packed_floats(int kind, int cin, int cout);
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev,
                         void* stream);

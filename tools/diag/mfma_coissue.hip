@@ -9,6 +9,13 @@
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// -DBF16_STREAM: the MFMA stream is v_mfma_f32_32x32x16_bf16 (32 cycles each) instead of v_mfma_f32_32x32x2_f32 (64 cycles)
+#ifdef BF16_STREAM
+#define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, make_float4(a_, a_, b_, b_)), __builtin_bit_cast(bf16x8, make_float4(b_, a_, b_, a_)), c_, 0, 0, 0)
+#else
+#define MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x2f32(a_, b_, c_, 0, 0, 0)
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 // MF: 0 no MFMA neighbour, 1 pure MFMA stream, 2 MFMA stream with 2 v_pk_fma per 4 MFMAs (the K loop's own VALU),
@@ -161,10 +168,10 @@ __global__ __launch_bounds__(256, 2) void k(const float* __restrict__ src, float
         if (MF == 17) {
           asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n v_mfma_f32_32x32x2_f32 %0, %3, %2, %0\n v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n v_mfma_f32_32x32x2_f32 %0, %3, %2, %0" : "+a"(acc[q]) : "v"(a0), "v"(b), "v"(a1));
         } else {
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(use ? e0.x : a0, b, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(use ? e0.y : a1, b, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(use ? e1.x : a0, b, acc[q], 0, 0, 0);
-        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(use ? e1.y : a1, b, acc[q], 0, 0, 0);
+        acc[q] = MFMA(use ? e0.x : a0, b, acc[q]);
+        acc[q] = MFMA(use ? e0.y : a1, b, acc[q]);
+        acc[q] = MFMA(use ? e1.x : a0, b, acc[q]);
+        acc[q] = MFMA(use ? e1.y : a1, b, acc[q]);
         }
       }
     }
@@ -196,17 +203,14 @@ template <int VK> void run(const char* name, const float* src, float* out, unsig
   const int iters = 60, reps = 16;  // MFMA stream: 60 x 32 x 64 = 122,880 cycles
   unsigned long long m[12], t[12];
   t[0] = run1<VK, 0>(src, out, clk, iters, reps, &m[0]);
-  t[1] = run1<VK, 13>(src, out, clk, iters, reps, &m[1]);
-  t[2] = run1<VK, 30>(src, out, clk, iters, reps, &m[2]);
-  t[3] = run1<VK, 31>(src, out, clk, iters, reps, &m[3]);
-  t[4] = run1<VK, 32>(src, out, clk, iters, reps, &m[4]);
-  t[5] = run1<VK, 33>(src, out, clk, iters, reps, &m[5]);
-  t[6] = run1<VK, 34>(src, out, clk, iters, reps, &m[6]);
-  t[7] = run1<VK, 35>(src, out, clk, iters, reps, &m[7]);
-  t[8] = run1<VK, 36>(src, out, clk, iters, reps, &m[8]);
+  t[1] = run1<VK, 1>(src, out, clk, iters, reps, &m[1]);
+  t[2] = run1<VK, 13>(src, out, clk, iters, reps, &m[2]);
+  t[3] = run1<VK, 4>(src, out, clk, iters, reps, &m[3]);
+  t[4] = run1<VK, 6>(src, out, clk, iters, reps, &m[4]);
+  t[5] = run1<VK, 7>(src, out, clk, iters, reps, &m[5]);
   printf("%-30s alone %6llu |", name, t[0]);
-  const char* nm[] = {"", "v_nop", "v_nop; s_barrier", "v_nop; s_sleep 1", "v_nop; s_waitcnt 0", "v_nop; 20 x s_nop 15", "ONE v_nop in the run", "v_nop; taken s_branch", "v_nop; s_sleep 8"};
-  for (int i = 1; i < 9; ++i) printf(" %s x%.2f (mfma %llu) |", nm[i], (double)t[i] / t[0], m[i]);
+  const char* nm[] = {"", "pure MFMA", "1 v_nop / 32 MFMA", "2 pk_fma / 4 MFMA", "1 LDS read / 4 MFMA", "1 global load / 4 MFMA"};
+  for (int i = 1; i < 6; ++i) printf(" %s x%.2f (mfma %llu) |", nm[i], (double)t[i] / t[0], m[i]);
   printf("\n");
 }
 
