@@ -134,3 +134,28 @@ def test_x6_rows_of_a_large_batch_match_a_small_batch():
         y, st = run_x6(kind, x, None, w, b)
         y2, st2 = run_x6(kind, x[592:].contiguous(), None, w, b)
         assert torch.equal(y[592:], y2) and torch.equal(st[592:], st2)
+
+
+def test_x6_model_forward_matches_fp32_mfma_forward_and_oracle(monkeypatch):
+    """UNetMini.forward (model.py:120-151) with the 4x4 convolutions on the bf16 pipe (default, DM_X6=7) against the same
+    weights on the fp32-MFMA kernels only (DM_X6=0) and against the CPU oracle: the split-bf16 form moves eps by less
+    than the fp32 kernels' own distance from the oracle."""
+    import diffusion_model_amd as d
+    from oracle import unet_oracle as O
+    d.set_seed(11)
+    monkeypatch.setenv("DM_X6", "0")
+    m0 = d.UNetMini(image_size=32).eval()
+    m0._native()                                          # (the handle reads DM_X6 when it is created)
+    monkeypatch.setenv("DM_X6", "7")
+    m7 = d.UNetMini(image_size=32).eval()
+    m7._native()
+    m7.load_state_dict(m0.state_dict())
+    x = torch.randn(24, 1, 32, 32)
+    t = torch.tensor(437)
+    with torch.no_grad():
+        e0 = m0(x.to(DEV), t.to(DEV)).cpu()
+        e7 = m7(x.to(DEV), t.to(DEV)).cpu()
+        ref = O.unet_forward({k: v.detach().cpu() for k, v in m0.state_dict().items()}, x, t)
+    assert not torch.equal(e0, e7)                       # (two different kernels did run)
+    assert (e0 - e7).abs().max().item() <= 2e-5
+    assert (e7 - ref).abs().max().item() <= 1e-4 and (e0 - ref).abs().max().item() <= 1e-4
