@@ -197,7 +197,7 @@ int launch_conv_x6_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
-  constexpr bool UP = (KIND == 4);
+  constexpr bool UP = (KIND == 4 || KIND == 2);
   const int cls = KIND == 0 ? DM_K_X6_CONV3 : KIND == 1 ? DM_K_X6_DOWN : DM_K_X6_UP;
   const double opix = (double)a.B * a.Hb * a.Wb * (UP ? 4 : 1);
   const double ipix = (double)a.B * a.H * a.W;
@@ -222,13 +222,14 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   if (kind == 1 && (c.H < 2 || c.W < 2)) return fail("conv: stride-2 conv needs H,W >= 2");
   if (c.stats_in && c.c2) return fail("conv: input transform and channel concat are exclusive");
   if (c.B <= 0) return fail("conv: empty batch");
-  if (kind == 2 && (c.H * c.W < 16 || cin != 64)) return fail("conv (split-bf16): transposed conv needs >= 16 input pixels and 64 input channels");
+  if (kind == 2 && c.H * c.W < 16) return fail("conv (split-bf16): transposed conv needs >= 16 input pixels");
+  const bool fused_up = kind == 2 && cin == 64;  // one K chunk: all four parities from one tile; else one parity per workgroup (grid.z)
   ConvGeo g = conv_geo(c.kind, c.H, c.W, c.cout);
   if (c.stats_out && c.stats_cap && (size_t)c.B * g.pout * DM_GROUPS * 2 > c.stats_cap)
     return fail("conv: statistics buffer too small (%zu floats for %d images x %d partials)", c.stats_cap, c.B, g.pout);
   const int th = 1 << g.th_log, tw = 1 << g.tw_log;
   if (kind == 1) { g.hth = th + 1; g.htw = tw + 1; }        // one input phase at a time: (th+1) x (tw+1) pixels
-  if (kind == 2) { g.hth = th + 2; g.htw = tw + 2; }        // all four parities from one tile
+  if (kind == 2) { g.hth = th + (fused_up ? 2 : 1); g.htw = tw + (fused_up ? 2 : 1); }
   ConvArgs a;
   memset(&a, 0, sizeof a);
   a.x1 = c.x1; a.x2 = c.x2; a.wp = c.wp; a.bias = c.bias; a.y = c.y;
@@ -256,7 +257,7 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   const size_t lds = lds_f * sizeof(float);
   if (lds > 160 * 1024) return fail("conv (split-bf16): tile needs %zu B of LDS (> 160 KiB)", lds);
   const int groups = (c.B + g.ni - 1) / g.ni;
-  dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), 1u);
+  dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), (kind == 2 && !fused_up) ? 4u : 1u);
   a.ntiles = (int)grid.x;
   {
     static const unsigned slot_div = getenv("DM_DEBUG_SLOT_DIV") ? (unsigned)atoi(getenv("DM_DEBUG_SLOT_DIV")) : 1u;  // diagnostics only
@@ -275,6 +276,7 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
 #define DM_X6(MB_, K_) (sw ? launch_conv_x6_t<MB_, K_, true>(a, grid, lds, s) : launch_conv_x6_t<MB_, K_, false>(a, grid, lds, s))
   if (kind == 0) return g.MT == 128 ? DM_X6(2, 0) : DM_X6(1, 0);
   if (kind == 1) return g.MT == 128 ? DM_X6(2, 1) : DM_X6(1, 1);
+  if (!fused_up) return g.MT == 128 ? DM_X6(2, 2) : DM_X6(1, 2);
   return g.MT == 128 ? DM_X6(2, 4) : DM_X6(1, 4);
 #undef DM_X6
 }
@@ -711,7 +713,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     c.step_ptr = step_ptr; c.step_off = step_off;
     if (launch_conv(c, s)) return 1;
     const int kdn = (!m->bf16 && (h / 2) * (ww / 2) >= 256) ? 6 : 1;  // stride-2 conv: 128-pixel tiles from 16x16 outputs up
-    const bool xt = up ? ((x6 & 2) && h * ww >= 16 && C == 64) : ((x6 & 1) && (h / 2) * (ww / 2) >= 16);  // (transposed: single K chunk only)
+    const bool xt = up ? ((x6 & 2) && h * ww >= 16) : ((x6 & 1) && (h / 2) * (ww / 2) >= 16);
     base(up ? 2 : kdn, w.T2, C, nullptr, 0, xt ? o.trx : o.tr, o.trb, out, out_stats, h, ww);
     c.x6 = xt;
     with_tf(w.SB, kd, h, ww, o.g2, o.b2);

@@ -18,7 +18,8 @@
 //           (space-to-depth): one K chunk per phase, so a tile holds (th+1) x (tw+1) pixels of ONE phase at a time
 //           and every global read is a whole 256-byte pixel (the 16-channel chunks of conv_mfma_kernel<2,1,16>
 //           fetched each 128-byte line twice).
-//   KIND 4: ConvTranspose2d 4x4 s2 p1, all four output parities from one staged tile.
+//   KIND 4: ConvTranspose2d 4x4 s2 p1, all four output parities from one staged tile (64 input channels: one K chunk).
+//   KIND 2: ConvTranspose2d 4x4 s2 p1, one output parity per workgroup (blockIdx.z; any number of K chunks).
 #pragma once
 #include "dm_kernels_bf16.hip"
 
@@ -42,7 +43,7 @@ __device__ __forceinline__ void dm_split3(float a, float b, unsigned& s1, unsign
 template <int MB, int KIND>
 __device__ __forceinline__ void x6_epilogue_sw(const ConvArgs& p, f32x16 (&acc)[MB], float* scr, int par, int py, int px,
                                                int img0, int tin, int y0, int x0, int wm, int wn, int lane, int h, int tid, int wave) {
-  constexpr bool UP = (KIND == 4);
+  constexpr bool UP = (KIND == 4 || KIND == 2);
   constexpr int MT = 64 * MB;
   const int OW = (KIND == 1) ? (p.W >> 1) : UP ? (p.W << 1) : p.W;
   const int OH = (KIND == 1) ? (p.H >> 1) : UP ? (p.H << 1) : p.H;
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   constexpr int NTY = (KIND == 0) ? 3 : 2;     // taps per axis walked per chunk (KIND 1: 2x2 per phase)
   constexpr int NT = NTY * NTY;
   constexpr int NTW = (KIND == 0) ? 9 : (KIND == 1) ? 16 : 4;  // taps per parity in the packed weights
+  constexpr bool UPK = (KIND == 4 || KIND == 2);
   constexpr int NTOT = (KIND == 4) ? 16 : NT;
   constexpr int NJ = KC / 16;
   // staging items (8 channels = two 16-byte loads) per thread and batch: one batch covers the model's tiles without an
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
   const int Cin = p.C1 + p.C2;
-  int par = 0, py = 0, px = 0;
+  int par = (KIND == 2) ? (int)blockIdx.z : 0, py = par >> 1, px = par & 1;
   const int th = 1 << p.th_log, tw = 1 << p.tw_log;
   const int hth = p.hth, htw = p.htw;
   const int NP = p.ni * hth * htw;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   const int nb32 = p.Cout >> 5;
   const size_t jstride = (size_t)nb32 * 512;               // bf16 elements per (16 channels, all output channels)
   const size_t tapstride = (size_t)(Cin >> 4) * jstride;
-  const size_t split_off = (size_t)((KIND == 4) ? 4 * NTW : NTW) * tapstride;  // one split term's whole block
+  const size_t split_off = (size_t)(UPK ? 4 * NTW : NTW) * tapstride;  // one split term's whole block
   const int cchunks = Cin / KC;
   const int nchunks = (KIND == 1) ? 4 * cchunks : cchunks;  // KIND 1: (phase, channel chunk)
   const bf16_t* wpk = reinterpret_cast<const bf16_t*>(p.wp);
@@ -208,8 +210,8 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
       const int pa = ph >> 1, pb = ph & 1;
       // KIND 1: plane pixel (Y, X) of phase (a, b) is input pixel (2 y0 - a + 2 Y, 2 x0 - b + 2 X); its taps are
       // ky = 2 ty + 1 - a, kx = 2 tx + 1 - b  (output (y, x) reads input rows 2y - 1 + ky)
-      const int hy0 = (KIND == 1) ? 2 * y0 - pa : y0 - 1;
-      const int hx0 = (KIND == 1) ? 2 * x0 - pb : x0 - 1;
+      const int hy0 = (KIND == 1) ? 2 * y0 - pa : (KIND == 2) ? y0 - 1 + py : y0 - 1;
+      const int hx0 = (KIND == 1) ? 2 * x0 - pb : (KIND == 2) ? x0 - 1 + px : x0 - 1;
       const int cg0 = cch * KC;
       const bool from2 = cg0 >= p.C1;
       const float* src = from2 ? p.x2 : p.x1;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
       const int coff = from2 ? cg0 - p.C1 : cg0;
       // wave-uniform weight pointer (scalar registers) + one 32-bit lane byte offset: saddr-form loads, no 64-bit vector adds
       const int wn_s = __builtin_amdgcn_readfirstlane(wn);
-      const bf16_t* wbase = wpk + (size_t)cch * NJ * jstride + (size_t)(blockIdx.y * 2 + wn_s) * 512;
+      const bf16_t* wbase = wpk + (size_t)((KIND == 2) ? par * NT : 0) * tapstride + (size_t)cch * NJ * jstride + (size_t)(blockIdx.y * 2 + wn_s) * 512;
       const unsigned lane16 = (unsigned)lane * 16u;
       if (chunk > 0) {
         DM_TL(5);
@@ -395,10 +397,10 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
     if constexpr (KIND != 4) {
       __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
       if constexpr (SW) {  // registers -> HBM; the reduction words sit behind the planes (no overlay, no barrier)
-        x6_epilogue_sw<MB, KIND>(p, acc, reinterpret_cast<float*>(tile + 3 * PL), 0, 0, 0, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
+        x6_epilogue_sw<MB, KIND>(p, acc, reinterpret_cast<float*>(tile + 3 * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
       } else {
         __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
-        conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, 0, 0, 0, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, bias_lane, true);
+        conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, bias_lane, true);
       }
     }
     __syncthreads();  // output staging / reduction words are free again for the next tile

@@ -71,14 +71,16 @@ def test_x6_conv_plain(kind, B, H):
 
 
 @pytest.mark.parametrize("kind,B,H,cin,cout", [(7, 2, 16, 128, 64), (7, 2, 64, 256, 256), (8, 2, 64, 256, 256), (7, 3, 8, 512, 128),
-                                               (8, 2, 16, 128, 256), (7, 3, 4, 128, 64)])
+                                               (8, 2, 16, 128, 256), (7, 3, 4, 128, 64), (9, 2, 32, 256, 256), (9, 3, 8, 128, 64),
+                                               (9, 5, 4, 256, 128)])
 def test_x6_conv_wide_and_concat(kind, B, H, cin, cout):
     """Several K chunks, several 64-channel output tiles, GroupNorm groups of 8..32 channels; the two-pointer
-    channel concat (model.py:146-148) when cin = 2 * 64."""
+    channel concat (model.py:146-148) when cin = 2 * 64; the transposed conv with more than 64 input channels runs one
+    output parity per workgroup."""
     torch.manual_seed(kind + B + H + cin)
     x = torch.randn(B, cin, H, H)
     k = 3 if kind == 7 else 4
-    w = torch.randn(cout, cin, k, k) * (1.0 / (k * cin ** 0.5))
+    w = (torch.randn(cin, cout, k, k) if kind == 9 else torch.randn(cout, cin, k, k)) * (1.0 / (k * cin ** 0.5))
     b = torch.randn(cout)
     if cin == 128 and kind == 7:
         y, st = run_x6(kind, x[:, :64].contiguous(), x[:, 64:].contiguous(), w, b)
