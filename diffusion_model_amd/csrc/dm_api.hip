@@ -5,6 +5,7 @@
 #include "dm_kernels.hip"
 #include "dm_kernels_bf16.hip"
 #include "dm_kernels_x6.hip"
+#include "dm_kernels_init5.hip"
 #include "../../include/dm_sampler.h"
 
 #include <hip/hip_runtime.h>
@@ -459,6 +460,8 @@ struct dm_unet {
   size_t o_freqs, o_tm1w, o_tm1b, o_tm2w, o_tm2b, o_initw, o_initb;
   BlockOff blk[6];
   size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb, o_b0w, o_b3w, o_b0x, o_b3x;
+  size_t o_i5m, o_i5bq, o_i5w, o_i5b;  // init_conv composed with down1.conv1 (init5_kernel)
+  int init5;           // 1: that composition replaces the two layers where the tile geometry allows (env DM_INIT5, default 1)
   size_t total;
   std::vector<GraphEntry> graphs;
 };
@@ -655,6 +658,33 @@ int attention_block(const dm_unet* m, const float* P, int which, float* X, const
   return launch_conv(c, s);
 }
 
+// init_conv (model.py:90,135) and down1.conv1 (model.py:54) as one 5x5 convolution from the image (dm_kernels_init5.hip)
+int launch_init5(const dm_unet* m, const float* P, const float* x, float* y, float* stats, int B, int H, int W, hipStream_t s) {
+  Init5Args a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.w25 = P + m->o_i5w; a.bfull = P + m->o_i5b; a.m = P + m->o_i5m; a.bq = P + m->o_i5bq; a.y = y; a.stats_out = stats;
+  a.B = B; a.Cin = m->Cin; a.H = H; a.W = W; a.C = m->C;
+  a.tiles_x = W / 16; a.tiles_per_img = (H / 8) * (W / 16); a.ntiles = B * a.tiles_per_img;
+  a.g_log = ilog2(m->C / DM_GROUPS); a.out_half = m->bf16;
+  const size_t lds = (size_t)(((m->Cin * 240 + 3) & ~3) + m->Cin * 25 * 64 + 81 * m->Cin * 64 + 9 * 64 + 64 + 256 + 8) * sizeof(float);
+  static bool attr_done[DM_MAX_DEVICES] = {false};
+  const int dev = current_device();
+  if (!attr_done[dev]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&init5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done[dev] = true;
+  }
+  const unsigned per_cu = lds > 80 * 1024 ? 1u : lds > 40 * 1024 ? 2u : 4u;
+  unsigned gx = per_cu * cu_count(dev) / (unsigned)(m->C / 64);
+  if (gx < 1) gx = 1;
+  if (gx > (unsigned)a.ntiles) gx = (unsigned)a.ntiles;
+  const double pix = (double)B * H * W;
+  // booked as the two layers it replaces: 9 Cin C + 9 C C multiply-adds per pixel; bytes: image in, activation out
+  ProfScope ps(DM_K_INIT, s, 2.0 * pix * (9.0 * m->Cin * m->C + 9.0 * m->C * m->C), pix * (4.0 * m->Cin + (m->bf16 ? 2.0 : 4.0) * m->C));
+  hipLaunchKernelGGL(init5_kernel, dim3(gx, (unsigned)(m->C / 64)), dim3(256), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // One denoiser evaluation (everything after the time embedding): model.py:135-151.
 // heads: [.., 6, C] table; heads_img_stride = 6*C when every image has its own timestep
 // (training-style [B] t) else 0; in the sampling loop the table is indexed by the step
@@ -705,7 +735,12 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     if (k == 0 && fold_init) {
       c.init_x = x; c.init_w = P + m->o_initw; c.init_b = P + m->o_initb; c.init_cin = m->Cin;
     }
-    if (launch_conv(c, s)) return 1;
+    // down1.conv1 after init_conv: ONE 5x5 convolution from the image where the 3x3 kernel's tiles are 8x16 pixels of one
+    // image (so the consumer sees the same GroupNorm partial geometry)
+    const ConvGeo g1 = conv_geo(kd, h, ww, C);
+    if (k == 0 && fold_init && m->init5 && !xs && g1.th_log == 3 && g1.tw_log == 4 && g1.ni == 1) {
+      if (launch_init5(m, P, x, w.T1, w.SA, B, h, ww, s)) return 1;
+    } else if (launch_conv(c, s)) return 1;
     base(kd, w.T1, C, nullptr, 0, xs ? o.c2x : kd == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
     c.x6 = xs;
     with_tf(w.SA, kd, h, ww, o.g1, o.b1);
@@ -875,6 +910,7 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
   m->attn = attention ? 1 : 0;
   m->bf16 = 0;
   m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 15 : DM_X6_DEFAULT;
+  m->init5 = getenv("DM_INIT5") ? (atoi(getenv("DM_INIT5")) != 0) : 1;
   const int C = m->C, E = m->E;
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
@@ -895,6 +931,8 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
   }
   m->o_b0w = take(conv_packed_floats(5, C, C)); m->o_b3w = take(conv_packed_floats(5, C, C));
   m->o_b0x = take(conv_packed_floats(7, C, C)); m->o_b3x = take(conv_packed_floats(7, C, C));
+  m->o_i5m = take((size_t)81 * m->Cin * C); m->o_i5bq = take((size_t)9 * C);
+  m->o_i5w = take((size_t)25 * m->Cin * C); m->o_i5b = take(C);
   m->o_b0 = take(conv_packed_floats(0, C, C)); m->o_b0b = take(C);
   m->o_bg = take(C); m->o_bb = take(C);
   m->o_b3 = take(conv_packed_floats(0, C, C)); m->o_b3b = take(C);
@@ -946,6 +984,14 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
   if (copy(m->o_tm1w, p[i++], (size_t)E * E) || copy(m->o_tm1b, p[i++], E) ||
       copy(m->o_tm2w, p[i++], (size_t)E * E) || copy(m->o_tm2b, p[i++], E) ||
       copy(m->o_initw, p[i++], (size_t)C * m->Cin * 9) || copy(m->o_initb, p[i++], C)) return 1;
+  {  // init_conv o down1.conv1 as one 5x5 convolution (dm_kernels_init5.hip): p[4], p[5] = init_conv, p[8], p[9] = down1.conv1
+    const size_t n1 = (size_t)81 * m->Cin * C + (size_t)9 * C, n2 = (size_t)25 * m->Cin * C + C;
+    hipLaunchKernelGGL(pack_init5_m_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, p[4], p[5], p[8], m->Cin, C,
+                       packed + m->o_i5m, packed + m->o_i5bq);
+    hipLaunchKernelGGL(pack_init5_w_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, p[4], p[5], p[8], p[9], m->Cin, C,
+                       packed + m->o_i5w, packed + m->o_i5b);
+    HIP_TRY(hipGetLastError());
+  }
   auto do_block = [&](int k) -> int {
     const bool up = k >= 3;
     const BlockOff& b = m->blk[k];
