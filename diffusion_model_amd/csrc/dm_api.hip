@@ -460,7 +460,7 @@ struct dm_unet {
   size_t o_freqs, o_tm1w, o_tm1b, o_tm2w, o_tm2b, o_initw, o_initb;
   BlockOff blk[6];
   size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb, o_b0w, o_b3w, o_b0x, o_b3x;
-  size_t o_i5m, o_i5bq, o_i5w, o_i5b;  // init_conv composed with down1.conv1 (init5_kernel)
+  size_t o_i5w;        // init_conv composed with down1.conv1: nine weight sets (init5_kernel)
   int init5;           // 1: that composition replaces the two layers where the tile geometry allows (env DM_INIT5, default 1)
   size_t total;
   std::vector<GraphEntry> graphs;
@@ -658,29 +658,39 @@ int attention_block(const dm_unet* m, const float* P, int which, float* X, const
   return launch_conv(c, s);
 }
 
-// init_conv (model.py:90,135) and down1.conv1 (model.py:54) as one 5x5 convolution from the image (dm_kernels_init5.hip)
+// init_conv (model.py:90,135) and down1.conv1 (model.py:54) as one 5x5 convolution from the image (dm_kernels_init5.hip).
+// LDS bytes it needs for an HxW image (0: geometry not covered -> the caller keeps the two-layer form).
+size_t init5_lds(const dm_unet* m, int H, int W) {
+  if (H < 16 || W < 16 || H % 8 || W % 16) return 0;      // (H >= 16: a tile position has at most one special row class)
+  const int sets = 2 * (W == 16 ? 3 : 2);
+  const size_t f = (size_t)((m->Cin * 240 + 3) & ~3) + (size_t)sets * (25 * m->Cin + 1) * 64 + 72;
+  return f * sizeof(float) <= 150 * 1024 ? f * sizeof(float) : 0;
+}
+
 int launch_init5(const dm_unet* m, const float* P, const float* x, float* y, float* stats, int B, int H, int W, hipStream_t s) {
   Init5Args a;
   memset(&a, 0, sizeof a);
-  a.x = x; a.w25 = P + m->o_i5w; a.bfull = P + m->o_i5b; a.m = P + m->o_i5m; a.bq = P + m->o_i5bq; a.y = y; a.stats_out = stats;
+  a.x = x; a.wc = P + m->o_i5w; a.y = y; a.stats_out = stats;
   a.B = B; a.Cin = m->Cin; a.H = H; a.W = W; a.C = m->C;
-  a.tiles_x = W / 16; a.tiles_per_img = (H / 8) * (W / 16); a.ntiles = B * a.tiles_per_img;
+  a.tiles_x = W / 16; a.tiles_per_img = (H / 8) * (W / 16);
   a.g_log = ilog2(m->C / DM_GROUPS); a.out_half = m->bf16;
-  const size_t lds = (size_t)(((m->Cin * 240 + 3) & ~3) + m->Cin * 25 * 64 + 81 * m->Cin * 64 + 9 * 64 + 64 + 256 + 8) * sizeof(float);
+  const size_t lds = init5_lds(m, H, W);
+  if (!lds) return fail("init5: geometry %dx%d not covered", H, W);
   static bool attr_done[DM_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&init5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
-  const unsigned per_cu = lds > 80 * 1024 ? 1u : lds > 40 * 1024 ? 2u : 4u;
-  unsigned gx = per_cu * cu_count(dev) / (unsigned)(m->C / 64);
-  if (gx < 1) gx = 1;
-  if (gx > (unsigned)a.ntiles) gx = (unsigned)a.ntiles;
+  // workgroups keep one tile position: grid.x = tiles_per_img x (images walked in parallel)
+  const unsigned per_cu = lds > 80 * 1024 ? 1u : lds > 53 * 1024 ? 2u : lds > 40 * 1024 ? 3u : 4u;
+  unsigned par = per_cu * cu_count(dev) / (unsigned)(a.tiles_per_img * (m->C / 64));
+  if (par < 1) par = 1;
+  if (par > (unsigned)B) par = (unsigned)B;
   const double pix = (double)B * H * W;
   // booked as the two layers it replaces: 9 Cin C + 9 C C multiply-adds per pixel; bytes: image in, activation out
   ProfScope ps(DM_K_INIT, s, 2.0 * pix * (9.0 * m->Cin * m->C + 9.0 * m->C * m->C), pix * (4.0 * m->Cin + (m->bf16 ? 2.0 : 4.0) * m->C));
-  hipLaunchKernelGGL(init5_kernel, dim3(gx, (unsigned)(m->C / 64)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(init5_kernel, dim3(par * a.tiles_per_img, (unsigned)(m->C / 64)), dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -738,7 +748,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     // down1.conv1 after init_conv: ONE 5x5 convolution from the image where the 3x3 kernel's tiles are 8x16 pixels of one
     // image (so the consumer sees the same GroupNorm partial geometry)
     const ConvGeo g1 = conv_geo(kd, h, ww, C);
-    if (k == 0 && fold_init && m->init5 && !xs && g1.th_log == 3 && g1.tw_log == 4 && g1.ni == 1) {
+    if (k == 0 && fold_init && m->init5 && !xs && g1.th_log == 3 && g1.tw_log == 4 && g1.ni == 1 && init5_lds(m, h, ww)) {
       if (launch_init5(m, P, x, w.T1, w.SA, B, h, ww, s)) return 1;
     } else if (launch_conv(c, s)) return 1;
     base(kd, w.T1, C, nullptr, 0, xs ? o.c2x : kd == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
@@ -931,8 +941,7 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
   }
   m->o_b0w = take(conv_packed_floats(5, C, C)); m->o_b3w = take(conv_packed_floats(5, C, C));
   m->o_b0x = take(conv_packed_floats(7, C, C)); m->o_b3x = take(conv_packed_floats(7, C, C));
-  m->o_i5m = take((size_t)81 * m->Cin * C); m->o_i5bq = take((size_t)9 * C);
-  m->o_i5w = take((size_t)25 * m->Cin * C); m->o_i5b = take(C);
+  m->o_i5w = take((size_t)9 * (25 * m->Cin + 1) * C);
   m->o_b0 = take(conv_packed_floats(0, C, C)); m->o_b0b = take(C);
   m->o_bg = take(C); m->o_bb = take(C);
   m->o_b3 = take(conv_packed_floats(0, C, C)); m->o_b3b = take(C);
@@ -985,11 +994,9 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
       copy(m->o_tm2w, p[i++], (size_t)E * E) || copy(m->o_tm2b, p[i++], E) ||
       copy(m->o_initw, p[i++], (size_t)C * m->Cin * 9) || copy(m->o_initb, p[i++], C)) return 1;
   {  // init_conv o down1.conv1 as one 5x5 convolution (dm_kernels_init5.hip): p[4], p[5] = init_conv, p[8], p[9] = down1.conv1
-    const size_t n1 = (size_t)81 * m->Cin * C + (size_t)9 * C, n2 = (size_t)25 * m->Cin * C + C;
-    hipLaunchKernelGGL(pack_init5_m_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, p[4], p[5], p[8], m->Cin, C,
-                       packed + m->o_i5m, packed + m->o_i5bq);
-    hipLaunchKernelGGL(pack_init5_w_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, p[4], p[5], p[8], p[9], m->Cin, C,
-                       packed + m->o_i5w, packed + m->o_i5b);
+    const size_t n1 = (size_t)9 * (25 * m->Cin + 1) * C;
+    hipLaunchKernelGGL(pack_init5_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, p[4], p[5], p[8], p[9], m->Cin, C,
+                       packed + m->o_i5w);
     HIP_TRY(hipGetLastError());
   }
   auto do_block = [&](int k) -> int {
