@@ -18,6 +18,16 @@
 #pragma once
 #include "dm_kernels.hip"
 
+// acc.xy += w.xy * x.lo / x.hi: v_pk_fma_f32 with the scalar operand broadcast by op_sel (hipcc copies a scalar that sits in
+// an odd register to an even one before every use - half the x values, one v_mov per packed FMA)
+typedef float i5_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void i5_fma_lo(i5_f2& acc, i5_f2 w, i5_f2 x) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "v"(x));
+}
+__device__ __forceinline__ void i5_fma_hi(i5_f2& acc, i5_f2 w, i5_f2 x) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(x));
+}
+
 struct Init5Args {
   const float* x;        // [B, Cin, H, W]
   const float* wc;       // [3 rc][3 cc][25 Cin + 1][C]  (row 25 Cin = the bias)
@@ -32,7 +42,7 @@ struct Init5Args {
 // Block = 256 threads = 16 pixel columns x 16 channel quads; a thread owns one column (8 pixels) x 4 channels of a tile.
 // A workgroup keeps ONE tile position (blockIdx.x % tiles_per_img) and walks the images: the weight sets it needs — interior
 // plus at most one special row class and the special column classes of that position — are loaded into LDS once.
-__global__ __launch_bounds__(256, 2) void init5_kernel(const Init5Args p) {
+__global__ __launch_bounds__(256, 3) void init5_kernel(const Init5Args p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int PH = 12, PW = 20;               // image patch: (8 + 4) x (16 + 4)
   const int Cin = p.Cin;
@@ -67,44 +77,60 @@ __global__ __launch_bounds__(256, 2) void init5_kernel(const Init5Args p) {
   const float inv_cnt = 1.0f / (float)(128 << p.g_log);
   const int n_step = gridDim.x / p.tiles_per_img;
 
-  for (int n = blockIdx.x / p.tiles_per_img; n < p.B; n += n_step) {
-    __syncthreads();  // previous image's readers of xs are done (first pass: the weight sets are in LDS)
-    for (int i = tid; i < Cin * PH * PW; i += 256) {
+  // the patch of the NEXT image is fetched into registers while the current one is computed (<= 4 values per thread)
+  constexpr int NPF = 4;
+  float pf[NPF];
+  auto fetch = [&](int n) {
+#pragma unroll
+    for (int q = 0; q < NPF; ++q) {
+      const int i = tid + q * 256;
       const int px = i % PW, r = i / PW, py = r % PH, ci = r / PH;
       const int iy = y0 - 2 + py, ix = x0 - 2 + px;
       float v = 0.f;
-      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = p.x[(((size_t)n * Cin + ci) * p.H + iy) * p.W + ix];
-      xs[i] = v;
+      if (i < Cin * PH * PW && n < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        v = p.x[(((size_t)n * Cin + ci) * p.H + iy) * p.W + ix];
+      pf[q] = v;
     }
+  };
+  fetch(blockIdx.x / p.tiles_per_img);
+  for (int n = blockIdx.x / p.tiles_per_img; n < p.B; n += n_step) {
+    __syncthreads();  // previous image's readers of xs are done (first pass: the weight sets are in LDS)
+#pragma unroll
+    for (int q = 0; q < NPF; ++q)
+      if (tid + q * 256 < Cin * PH * PW) xs[tid + q * 256] = pf[q];
     __syncthreads();
+    fetch(n + n_step);
     // (opaque copies: the weights are read from LDS per image; hoisted out of the image loop they would take 200 registers)
     int oi = lc_t * SET, osp = ((1 + ncs) + lc_t) * SET;  // (integer offsets: an opaque POINTER would become a flat address)
     asm volatile("" : "+v"(oi), "+v"(osp));
     const float* wi = ws + oi;
     const float* wsp = ws + osp;
     const float4 bf = *reinterpret_cast<const float4*>(wi + 25 * Cin * 64 + c4 * 4);
-    float4 acc[8];
+    i5_f2 a01[8], a23[8];  // channels (0,1) and (2,3) of the thread's quad, per pixel
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = bf;
-    float4 asp = rsp ? *reinterpret_cast<const float4*>(wsp + 25 * Cin * 64 + c4 * 4) : bf;  // the special row's pixel, recomputed
+    for (int k = 0; k < 8; ++k) { a01[k] = i5_f2{bf.x, bf.y}; a23[k] = i5_f2{bf.z, bf.w}; }
+    float4 aspv = rsp ? *reinterpret_cast<const float4*>(wsp + 25 * Cin * 64 + c4 * 4) : bf;  // the special row's pixel, recomputed
+    i5_f2 s01 = {aspv.x, aspv.y}, s23 = {aspv.z, aspv.w};
     for (int ci = 0; ci < Cin; ++ci) {
-      float xv[PH][5];  // this column's window: rows 0..11, columns col..col+4
+      i5_f2 xv[PH][3];  // this column's window: rows 0..11, columns col..col+5 as pairs (the sixth is not used)
 #pragma unroll
       for (int r = 0; r < PH; ++r)
 #pragma unroll
-        for (int c = 0; c < 5; ++c) xv[r][c] = xs[(ci * PH + r) * PW + col + c];
+        for (int c = 0; c < 3; ++c) {
+          const float* q = xs + (ci * PH + r) * PW + col + 2 * c;
+          xv[r][c] = i5_f2{q[0], c < 2 ? q[1] : 0.f};
+        }
 #pragma unroll
       for (int dy = 0; dy < 5; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 5; ++dx) {
           const float4 w = *reinterpret_cast<const float4*>(wi + ((ci * 25 + dy * 5 + dx) * 64) + c4 * 4);
+          const i5_f2 w01 = {w.x, w.y}, w23 = {w.z, w.w};
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
-            const float v = xv[k + dy][dx];
-            acc[k].x = fmaf(w.x, v, acc[k].x); acc[k].y = fmaf(w.y, v, acc[k].y);
-            acc[k].z = fmaf(w.z, v, acc[k].z); acc[k].w = fmaf(w.w, v, acc[k].w);
+            if (dx & 1) { i5_fma_hi(a01[k], w01, xv[k + dy][dx >> 1]); i5_fma_hi(a23[k], w23, xv[k + dy][dx >> 1]); }
+            else { i5_fma_lo(a01[k], w01, xv[k + dy][dx >> 1]); i5_fma_lo(a23[k], w23, xv[k + dy][dx >> 1]); }
           }
-          if (dx == 4) __builtin_amdgcn_sched_barrier(0);  // one row of taps at a time: hipcc otherwise hoists all 25 weight quads (100 registers)
         }
       if (rsp) {  // (uniform) first row of a top tile / last row of a bottom tile: its own weight set
 #pragma unroll
@@ -112,12 +138,17 @@ __global__ __launch_bounds__(256, 2) void init5_kernel(const Init5Args p) {
 #pragma unroll
           for (int dx = 0; dx < 5; ++dx) {
             const float4 w = *reinterpret_cast<const float4*>(wsp + ((ci * 25 + dy * 5 + dx) * 64) + c4 * 4);
-            const float v = (rsp == 1) ? xv[dy][dx] : xv[7 + dy][dx];
-            asp.x = fmaf(w.x, v, asp.x); asp.y = fmaf(w.y, v, asp.y); asp.z = fmaf(w.z, v, asp.z); asp.w = fmaf(w.w, v, asp.w);
-            if (dx == 4) __builtin_amdgcn_sched_barrier(0);
+            const i5_f2 w01 = {w.x, w.y}, w23 = {w.z, w.w};
+            const i5_f2 v = (rsp == 1) ? xv[dy][dx >> 1] : xv[7 + dy][dx >> 1];
+            if (dx & 1) { i5_fma_hi(s01, w01, v); i5_fma_hi(s23, w23, v); }
+            else { i5_fma_lo(s01, w01, v); i5_fma_lo(s23, w23, v); }
           }
       }
     }
+    float4 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = make_float4(a01[k].x, a01[k].y, a23[k].x, a23[k].y);
+    const float4 asp = make_float4(s01.x, s01.y, s23.x, s23.y);
     if (rsp == 1) acc[0] = asp;
     if (rsp == 2) acc[7] = asp;
     // GroupNorm (mean, M2) partial of this tile: two passes; lanes of a group meet by shuffles, the four waves through LDS
