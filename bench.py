@@ -166,6 +166,33 @@ def run_configs(d, O, dev, sd32):
     m32._ws = None
     torch.cuda.empty_cache()
 
+    # ---- configs[1] again with the OPT-IN two-term operand split of the 4x4 convolutions (DM_X6 bit 4: three bf16 MFMAs per
+    # product instead of six; ~7x the rounding error of an fp32 dot product in those layers).  NOT the default and not `value`.
+    if "DM_X6" not in os.environ:
+        os.environ["DM_X6"] = "23"
+        try:
+            m2t = d.UNetMini(image_size=32).eval()
+            m2t._native()  # (the handle reads DM_X6 when it is created)
+        finally:
+            del os.environ["DM_X6"]
+        m2t.load_state_dict(sd32)
+        B, n = 1024, 50
+        x_T = torch.randn((B, 1, 32, 32), generator=torch.Generator().manual_seed(15))
+        xd = x_T.to(dev)
+        dt, out = timed_passes(lambda: smp.sample_from(m2t, xd), 3)
+        k = 8
+        ref = O.sample(sd32, osch, (k, 1, 32, 32), n, 0.0, x_T=x_T[-k:])
+        dflt = smp.sample_from(m32, xd)
+        res["cfg2_optin_two_term_split_fp32"] = {
+            "images_per_s": B / dt, "ms_per_pass": 1e3 * dt, "batch": B, "steps": n,
+            "check_max_abs_vs_cpu_oracle": (out[-k:].cpu() - ref).abs().max().item(),
+            "default_build_same_inputs_check_max_abs_vs_cpu_oracle": (dflt[-k:].cpu() - ref).abs().max().item(),
+            "check": f"last {k} images, all {n} steps (tolerance 1e-4 on eps per step; PSNR >= 40 dB on the samples)",
+            "note": "opt-in (DM_X6=23): operands of the 4x4 convolutions as two bf16 terms, 3 MFMAs per product; the default (`value`) uses "
+                    "three terms and six MFMAs, whose error is at the level of fp32 rounding"}
+        del out, dflt, xd, m2t
+        torch.cuda.empty_cache()
+
     # ---- cfg4: class-conditional + classifier-free guidance (doubled batch), bf16 (configs[3]; build-defined semantics)
     B, n, w = 1024, 50, 3.0
     mb = d.UNetMini(image_size=32, precision="bf16").eval()

@@ -141,7 +141,7 @@ struct ConvCall {
   int B, H, W;
   const float* res; int no_silu;
   int bf16;  // activations and packed weights are bf16 (conv_bf16_kernel)
-  int x6;    // fp32 activations, weights packed as three bf16 split terms (conv_x6_kernel); kinds 0, 1/6, 2
+  int x6;    // fp32 activations, weights packed as three bf16 split terms (conv_x6_kernel); kinds 0, 1/6, 2; 2: two-term form (opt-in)
   const float* init_x; const float* init_w; const float* init_b; int init_cin;  // folded init_conv
 };
 
@@ -189,12 +189,12 @@ int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
   return 0;
 }
 
-template <int MB, int KIND, bool SW>
+template <int MB, int KIND, bool SW, int NS = 3>
 int launch_conv_x6_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_done[DM_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MB, KIND, SW>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MB, KIND, SW, NS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
@@ -205,7 +205,7 @@ int launch_conv_x6_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : 4;
   const int cin = a.C1 + a.C2;
   ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 4.0 * (ipix * cin + opix * a.Cout) + 6.0 * taps * (UP ? 4 : 1) * cin * a.Cout);
-  hipLaunchKernelGGL((conv_x6_kernel<MB, KIND, SW>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_x6_kernel<MB, KIND, SW, NS>), grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -253,7 +253,8 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   const size_t np = (size_t)g.ni * g.hth * g.htw;
   if (np * 8 > 3 * 256 * 8) return fail("conv (split-bf16): tile of %zu halo pixels is too large", np);
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
-  size_t lds_f = (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (3 * np * 72 + 1) / 2 + 128;  // + reduction words behind the planes
+  const int ns = c.x6 == 2 ? 2 : 3;  // split terms per operand
+  size_t lds_f = (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (ns * np * 72 + 1) / 2 + 128;  // + reduction words behind the planes
   if (lds_f < epi_f) lds_f = epi_f;
   const size_t lds = lds_f * sizeof(float);
   if (lds > 160 * 1024) return fail("conv (split-bf16): tile needs %zu B of LDS (> 160 KiB)", lds);
@@ -274,7 +275,8 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
 #endif
   // one image per tile: swapped MFMA operands, stores straight from the registers (x6_epilogue_sw)
   const bool sw = g.ni == 1 && getenv("DM_DEBUG_NOSWAP") == nullptr;
-#define DM_X6(MB_, K_) (sw ? launch_conv_x6_t<MB_, K_, true>(a, grid, lds, s) : launch_conv_x6_t<MB_, K_, false>(a, grid, lds, s))
+#define DM_X6(MB_, K_) (ns == 2 ? (sw ? launch_conv_x6_t<MB_, K_, true, 2>(a, grid, lds, s) : launch_conv_x6_t<MB_, K_, false, 2>(a, grid, lds, s)) \
+                               : (sw ? launch_conv_x6_t<MB_, K_, true>(a, grid, lds, s) : launch_conv_x6_t<MB_, K_, false>(a, grid, lds, s)))
   if (kind == 0) return g.MT == 128 ? DM_X6(2, 0) : DM_X6(1, 0);
   if (kind == 1) return g.MT == 128 ? DM_X6(2, 1) : DM_X6(1, 1);
   if (!fused_up) return g.MT == 128 ? DM_X6(2, 2) : DM_X6(1, 2);
@@ -734,6 +736,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   // 3x3 convolutions: Winograd F(2x2,3x3) in fp32 from 8x8 up, the direct form below that and in bf16
   // (split-bf16 form, conv_x6_kernel: where m->x6 selects it)
   // (not below 16 pixels per image: 16-64 single-pixel images with their halos do not fit the CU's LDS as three planes)
+  const int xmode = (x6 & 16) ? 2 : 1;  // bit 4: two-term splits (three MFMAs per product; about 7x the fp32 rounding error) - opt-in
   auto x3 = [&](int h, int ww) { return h * ww >= 16 && ((x6 & 8) || ((x6 & 4) && (h < 8 || ww < 8))); };
   auto k3 = [&](int h, int ww) { return (!m->bf16 && !x3(h, ww) && h >= 8 && ww >= 8) ? 5 : 0; };
   auto block = [&](int k, const float* in1, const float* in2, int h, int ww, bool up, float* out, float* out_stats) -> int {
@@ -741,7 +744,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     const int kd = k3(h, ww);
     const bool xs = x3(h, ww);
     base(kd, in1, C, in2, in2 ? C : 0, xs ? o.c1x : kd == 5 ? o.c1w : o.c1, o.c1b, w.T1, w.SA, h, ww);
-    c.x6 = xs;
+    c.x6 = xs ? xmode : 0;
     if (k == 0 && fold_init) {
       c.init_x = x; c.init_w = P + m->o_initw; c.init_b = P + m->o_initb; c.init_cin = m->Cin;
     }
@@ -752,7 +755,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
       if (launch_init5(m, P, x, w.T1, w.SA, B, h, ww, s)) return 1;
     } else if (launch_conv(c, s)) return 1;
     base(kd, w.T1, C, nullptr, 0, xs ? o.c2x : kd == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
-    c.x6 = xs;
+    c.x6 = xs ? xmode : 0;
     with_tf(w.SA, kd, h, ww, o.g1, o.b1);
     c.temb = heads + (size_t)k * C; c.temb_stride = heads_img_stride; c.temb_step_stride = heads_step_stride;
     c.step_ptr = step_ptr; c.step_off = step_off;
@@ -760,7 +763,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     const int kdn = (!m->bf16 && (h / 2) * (ww / 2) >= 256) ? 6 : 1;  // stride-2 conv: 128-pixel tiles from 16x16 outputs up
     const bool xt = up ? ((x6 & 2) && h * ww >= 16) : ((x6 & 1) && (h / 2) * (ww / 2) >= 16);
     base(up ? 2 : kdn, w.T2, C, nullptr, 0, xt ? o.trx : o.tr, o.trb, out, out_stats, h, ww);
-    c.x6 = xt;
+    c.x6 = xt ? xmode : 0;
     with_tf(w.SB, kd, h, ww, o.g2, o.b2);
     return launch_conv(c, s);
   };
@@ -775,10 +778,10 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   const int kb = k3(H / 8, W / 8);
   const bool xb = x3(H / 8, W / 8);
   base(kb, w.D3, C, nullptr, 0, xb ? m->o_b0x : kb == 5 ? m->o_b0w : m->o_b0, m->o_b0b, w.BT0, w.SA, H / 8, W / 8);
-  c.x6 = xb;
+  c.x6 = xb ? xmode : 0;
   if (launch_conv(c, s)) return 1;
   base(kb, w.BT0, C, nullptr, 0, xb ? m->o_b3x : kb == 5 ? m->o_b3w : m->o_b3, m->o_b3b, w.BT, nullptr, H / 8, W / 8);
-  c.x6 = xb;
+  c.x6 = xb ? xmode : 0;
   with_tf(w.SA, kb, H / 8, W / 8, m->o_bg, m->o_bb);
   if (launch_conv(c, s)) return 1;
   // up path: channel concat [upstream, skip] (model.py:146-148) handled by two input pointers
@@ -919,7 +922,7 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
   m->Cin = in_channels; m->Cout = out_channels; m->C = model_channels; m->E = time_emb_dim;
   m->attn = attention ? 1 : 0;
   m->bf16 = 0;
-  m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 15 : DM_X6_DEFAULT;
+  m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 31 : DM_X6_DEFAULT;
   m->init5 = getenv("DM_INIT5") ? (atoi(getenv("DM_INIT5")) != 0) : 1;
   const int C = m->C, E = m->E;
   size_t off = 0;

@@ -123,7 +123,9 @@ __device__ __forceinline__ void x6_epilogue_sw(const ConvArgs& p, f32x16 (&acc)[
   }
 }
 
-template <int MB, int KIND, bool SW = false>
+// NS = 3: the fp32-equivalent form above.  NS = 2 (opt-in, DM_X6 bit 4): two bf16 terms per operand and THREE MFMAs per product
+// (a1 b1 + a1 b2 + a2 b1): operands carry 16-17 mantissa bits, about 7x the rounding error of an fp32 dot product.
+template <int MB, int KIND, bool SW = false, int NS = 3>
 __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   constexpr int KC = 64;
   constexpr int MT = 64 * MB;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
               bf16_t* q = tile + pix * RSB + c8 * 8;
               *reinterpret_cast<uint4*>(q) = s1;
               *reinterpret_cast<uint4*>(q + PL) = s2;
-              *reinterpret_cast<uint4*>(q + 2 * PL) = s3;
+              if (NS == 3) *reinterpret_cast<uint4*>(q + 2 * PL) = s3;
             }
             __builtin_amdgcn_sched_barrier(0);  // one item's chain at a time (register peak)
           }
@@ -309,13 +311,13 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
         const int wt = (KIND == 1) ? ((2 * (tp >> 1) + 1 - pa) * 4 + 2 * (tp & 1) + 1 - pb) : tp;
         return wbase + (size_t)wt * tapstride;
       };
-      uint4 bq[NJ][3];
+      uint4 bq[NJ][NS];
       {
         const bf16_t* w0 = wtap(0);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int s = 0; s < 3; ++s) bq[j][s] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w0 + s * split_off + j * jstride) + lane16);
+          for (int s = 0; s < NS; ++s) bq[j][s] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w0 + s * split_off + j * jstride) + lane16);
       }
       __syncthreads();
       __builtin_amdgcn_s_setprio(DM_PRIO_K);
@@ -326,10 +328,10 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
       }
-      uint4 a0[3][MB], a1[3][MB];
-      const bf16_t* ap[3][MB];  // this lane's fragment address per plane at tap (0,0): per step only (tap offset) + immediate
+      uint4 a0[NS][MB], a1[NS][MB];
+      const bf16_t* ap[NS][MB];  // this lane's fragment address per plane at tap (0,0): per step only (tap offset) + immediate
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           ap[s][mb] = tile + s * PL + abase[mb];
@@ -360,21 +362,26 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
           // (small terms first); a weight term is reloaded for the next tap right after its last use.
           const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, bq[j][0]);
           const bf16x8_t b2 = __builtin_bit_cast(bf16x8_t, bq[j][1]);
-          const bf16x8_t b3 = __builtin_bit_cast(bf16x8_t, bq[j][2]);
+          const bf16x8_t b3 = __builtin_bit_cast(bf16x8_t, bq[j][NS - 1]);  // (NS = 2: unused)
           __builtin_amdgcn_sched_barrier(0);
+          constexpr int NTERM = (NS == 3) ? 6 : 3;  // NS = 2: a1b2, a2b1, a1b1
 #pragma unroll
-          for (int t = 0; t < 6; ++t) {
-            const int as = (t == 1 || t == 4) ? 1 : (t == 3) ? 2 : 0;
-            const bf16x8_t bv = (t == 0) ? b3 : (t == 1 || t == 2) ? b2 : b1;
+          for (int t = 0; t < NTERM; ++t) {
+            const int as = (NS == 3) ? ((t == 1 || t == 4) ? 1 : (t == 3) ? 2 : 0) : (t == 1 ? 1 : 0);
+            const bf16x8_t bv = (NS == 3) ? ((t == 0) ? b3 : (t == 1 || t == 2) ? b2 : b1) : (t == 0 ? b2 : b1);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
               const bf16x8_t av = __builtin_bit_cast(bf16x8_t, acur[as][mb]);
               acc[mb] = SW ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[mb], 0, 0, 0)
                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mb], 0, 0, 0);
-              if (t < 3) anxt[t][mb] = *reinterpret_cast<const uint4*>(ap[t][mb] + noff);
-              if (t == 3 && mb == 0) bq[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * split_off + j * jstride) + lane16);
-              if (t == 4 && mb == 0) bq[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + split_off + j * jstride) + lane16);
-              if (t == 5 && mb == MB - 1) bq[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + j * jstride) + lane16);
+              if (t < NS) anxt[t][mb] = *reinterpret_cast<const uint4*>(ap[t][mb] + noff);
+              if (NS == 3) {
+                if (t == 3 && mb == 0) bq[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * split_off + j * jstride) + lane16);
+                if (t == 4 && mb == 0) bq[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + split_off + j * jstride) + lane16);
+              } else {
+                if (t == 1 && mb == MB - 1) bq[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + split_off + j * jstride) + lane16);
+              }
+              if (t == NTERM - 1 && mb == MB - 1) bq[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + j * jstride) + lane16);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -383,8 +390,8 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
         if constexpr (KIND == 4) if ((tap & 3) == 3) {
           // one output parity is complete: registers -> HBM (the input tile stays in LDS for the next parity)
           par = tap >> 2; py = par >> 1; px = par & 1;
-          if constexpr (SW) x6_epilogue_sw<MB, 4>(p, acc, reinterpret_cast<float*>(tile + 3 * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
-          else conv_epilogue<MB, 4>(p, acc, reinterpret_cast<float*>(tile + 3 * PL), nullptr, par, py, px, img0, tin, y0, x0,
+          if constexpr (SW) x6_epilogue_sw<MB, 4>(p, acc, reinterpret_cast<float*>(tile + NS * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
+          else conv_epilogue<MB, 4>(p, acc, reinterpret_cast<float*>(tile + NS * PL), nullptr, par, py, px, img0, tin, y0, x0,
                                     wm, wn, lane, h, tid, wave, bias_lane, true);
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb)
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
     if constexpr (KIND != 4) {
       __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
       if constexpr (SW) {  // registers -> HBM; the reduction words sit behind the planes (no overlay, no barrier)
-        x6_epilogue_sw<MB, KIND>(p, acc, reinterpret_cast<float*>(tile + 3 * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
+        x6_epilogue_sw<MB, KIND>(p, acc, reinterpret_cast<float*>(tile + NS * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
       } else {
         __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
         conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, bias_lane, true);
