@@ -161,3 +161,30 @@ def test_x6_model_forward_matches_fp32_mfma_forward_and_oracle(monkeypatch):
     assert not torch.equal(e0, e7)                       # (two different kernels did run)
     assert (e0 - e7).abs().max().item() <= 2e-5
     assert (e7 - ref).abs().max().item() <= 1e-4 and (e0 - ref).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("size,cin,ch", [(32, 1, 64), (16, 1, 64), (64, 3, 128)])
+def test_init5_composed_first_layers_match_two_layer_form_and_oracle(monkeypatch, size, cin, ch):
+    """init_conv (model.py:135) and down1.conv1 (model.py:54) evaluated as ONE 5x5 convolution with border-class weight sets
+    (default) against the two-layer evaluation (DM_INIT5=0) and the CPU oracle; an input with large values along the image
+    border makes a wrong border class visible."""
+    import diffusion_model_amd as d
+    from oracle import unet_oracle as O
+    d.set_seed(21)
+    monkeypatch.setenv("DM_INIT5", "0")
+    m0 = d.UNetMini(image_size=size, in_channels=cin, out_channels=cin, model_channels=ch).eval()
+    m0._native()
+    monkeypatch.setenv("DM_INIT5", "1")
+    m1 = d.UNetMini(image_size=size, in_channels=cin, out_channels=cin, model_channels=ch).eval()
+    m1._native()
+    m1.load_state_dict(m0.state_dict())
+    x = torch.randn(5, cin, size, size)
+    x[:, :, 0, :] += 3.0; x[:, :, -1, :] -= 2.0; x[:, :, :, 0] += 2.5; x[:, :, :, -1] -= 3.5
+    t = torch.tensor(901)
+    with torch.no_grad():
+        e0 = m0(x.to(DEV), t.to(DEV)).cpu()
+        e1 = m1(x.to(DEV), t.to(DEV)).cpu()
+        ref = O.unet_forward({k: v.detach().cpu() for k, v in m0.state_dict().items()}, x, t)
+    assert not torch.equal(e0, e1)                        # (two different evaluations did run)
+    assert (e0 - e1).abs().max().item() <= 2e-5
+    assert (e1 - ref).abs().max().item() <= 1e-4 and (e0 - ref).abs().max().item() <= 1e-4
