@@ -14,7 +14,7 @@ f = load('gpurun_out/pmc_fetch/*/*counter_collection.csv', 'FETCH_SIZE')
 w = load('gpurun_out/pmc_write/*/*counter_collection.csv', 'WRITE_SIZE')
 per = {}
 for k in sorted(f):
-    if not (k.startswith('conv_') or k.startswith('final_') or k.startswith('sampler_') or k.startswith('attention')):
+    if not (k.startswith('conv_') or k.startswith('final_') or k.startswith('sampler_') or k.startswith('attention') or k.startswith('init5')):
         continue
     rd = 2 * 1024 * sum(f[k]) / len(f[k]); wr = 1024 * sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
     per[k] = {"launches": len(f[k]), "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
