@@ -264,11 +264,12 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   {
     static const unsigned slot_div = getenv("DM_DEBUG_SLOT_DIV") ? (unsigned)atoi(getenv("DM_DEBUG_SLOT_DIV")) : 1u;  // diagnostics only
     const unsigned per_cu = lds > 80 * 1024 ? 1u : (lds <= 53 * 1024 && g.MT == 64 && getenv("DM_DEBUG_X6_2WG") == nullptr) ? 3u : 2u;  // (64-pixel tiles: <= 159 registers)
-    const unsigned slots = per_cu * cu_count(current_device()) / (slot_div ? slot_div : 1u);
-    const unsigned resident = slots / grid.y ? slots / grid.y : 1u;
+    static const unsigned x6_pc = getenv("DM_DEBUG_X6_PER_CU") ? (unsigned)atoi(getenv("DM_DEBUG_X6_PER_CU")) : 0u;  // diagnostics only
+    const unsigned slots = (x6_pc && x6_pc < per_cu ? x6_pc : per_cu) * cu_count(current_device()) / (slot_div ? slot_div : 1u);
+    const unsigned resident = slots / (grid.y * grid.z) ? slots / (grid.y * grid.z) : 1u;
     if (grid.x > resident) grid.x = resident;
     a.ngroups = groups;
-    a.xcd_map = (grid.x % 8 == 0 && grid.y == 1 && groups >= 64) ? 1 : 0;
+    a.xcd_map = (grid.x % 8 == 0 && grid.y == 1 && grid.z == 1 && groups >= 64) ? 1 : 0;
   }
 #ifdef DM_STAMPS
   a.stamps = g_stamps;
