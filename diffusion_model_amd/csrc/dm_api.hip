@@ -141,6 +141,7 @@ struct ConvCall {
   int B, H, W;
   const float* res; int no_silu;
   int bf16;  // activations and packed weights are bf16 (conv_bf16_kernel)
+  int in_wrap;  // input images n >= in_wrap read image n - in_wrap (3x3 Winograd / bf16 3x3 kernel, one image per tile)
   int x6;    // fp32 activations, weights packed as three bf16 split terms (conv_x6_kernel); kinds 0, 1/6, 2; 2: two-term form (opt-in)
   const float* init_x; const float* init_w; const float* init_b; int init_cin;  // folded init_conv
 };
@@ -329,6 +330,10 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
   a.g1_log = ilog2(c.c1 / DM_GROUPS);
   a.init_x = c.init_x; a.init_w = c.init_w; a.init_b = c.init_b; a.init_cin = c.init_cin;
   if (c.init_x && ((c.kind != 0 && c.kind != 5) || c.stats_in || c.c2)) return fail("conv: folded init_conv needs a plain 3x3 conv");
+  if (c.in_wrap) {
+    if (g.ni != 1 || !(c.kind == 5 || (c.kind == 0 && c.bf16)) || c.c2 || c.init_x) return fail("conv: shared-input batches need a 3x3 layer with one image per tile");
+    a.in_wrap = c.in_wrap;
+  }
   const size_t init_f = c.init_x ? (size_t)g.ni * c.init_cin * (g.hth + 2) * (g.htw + 2) + 4 + (size_t)c.init_cin * 9 * 64 + 64 + 8 : 0;
 #ifdef DM_STAMPS
   a.stamps = g_stamps;
@@ -702,9 +707,11 @@ int launch_init5(const dm_unet* m, const float* P, const float* x, float* y, flo
 // heads: [.., 6, C] table; heads_img_stride = 6*C when every image has its own timestep
 // (training-style [B] t) else 0; in the sampling loop the table is indexed by the step
 // (step_ptr/step_off, stride 6*C per step, or 6*C*B with per-image heads).
+// dup_half > 0: images [dup_half, 2 dup_half) of x are copies of [0, dup_half) (guided sampling's doubled batch): the first
+// layers, which see no time / class embedding, are evaluated once and read by both halves.
 int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, const float* heads,
               int heads_img_stride, int heads_step_stride, const int* step_ptr, int step_off,
-              const Workspace& w, int B, int H, int W, hipStream_t s) {
+              const Workspace& w, int B, int H, int W, hipStream_t s, int dup_half = 0) {
   const int C = m->C;
   // init_conv (model.py:135) is folded into down1.conv1's staging (no kernel, no HBM round trip)
   // (also in bf16: the stand-alone init kernel + a plain first layer take 343 + 163 us at B = 2048, the folded layer 420)
@@ -752,11 +759,15 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     // down1.conv1 after init_conv: ONE 5x5 convolution from the image where the 3x3 kernel's tiles are 8x16 pixels of one
     // image (so the consumer sees the same GroupNorm partial geometry)
     const ConvGeo g1 = conv_geo(kd, h, ww, C);
+    bool shared1 = false;  // conv1's output holds dup_half images only
     if (k == 0 && fold_init && m->init5 && !xs && g1.th_log == 3 && g1.tw_log == 4 && g1.ni == 1 && init5_lds(m, h, ww)) {
-      if (launch_init5(m, P, x, w.T1, w.SA, B, h, ww, s)) return 1;
+      static const bool noshare = getenv("DM_DEBUG_NOSHARE") != nullptr;  // diagnostics only
+      shared1 = dup_half > 0 && B == 2 * dup_half && !noshare;
+      if (launch_init5(m, P, x, w.T1, w.SA, shared1 ? dup_half : B, h, ww, s)) return 1;
     } else if (launch_conv(c, s)) return 1;
     base(kd, w.T1, C, nullptr, 0, xs ? o.c2x : kd == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
     c.x6 = xs ? xmode : 0;
+    c.in_wrap = shared1 ? dup_half : 0;
     with_tf(w.SA, kd, h, ww, o.g1, o.b1);
     c.temb = heads + (size_t)k * C; c.temb_stride = heads_img_stride; c.temb_step_stride = heads_step_stride;
     c.step_ptr = step_ptr; c.step_off = step_off;
@@ -1163,7 +1174,7 @@ int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, co
     hipLaunchKernelGGL(dup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xc, w.xx, count);
     HIP_TRY(hipGetLastError());
     if (launch_time_embed(m, packed, w.ts, Bd, w.cond, nullptr, w.heads, s, step_ptr, step_off, 0)) return 1;
-    if (unet_body(m, packed, w.xx, w.eps, w.heads, hstep, 0, nullptr, 0, w, Bd, H, W, s)) return 1;
+    if (unet_body(m, packed, w.xx, w.eps, w.heads, hstep, 0, nullptr, 0, w, Bd, H, W, s, B)) return 1;
     return launch_step(xc, w.eps, noise ? w.noise : nullptr, local, w.coefs, step_ptr, step_off, nullptr, xc, count, 1, guidance, s);
   };
   // noise of steps [first, first + cnt) -> staging area (noise: [n][count], device or host memory)

@@ -112,6 +112,8 @@ struct ConvArgs {
   int ngroups;            // image groups (ceil(B / ni)); xcd_map: tiles are dealt to workgroups per XCD (see the tile loop)
   int xcd_map;
   int ntiles;             // tiles along grid.x (persistent kernels loop: t = blockIdx.x; t < ntiles; t += gridDim.x)
+  int in_wrap;            // > 0: input images n >= in_wrap read the activation and statistics of image n - in_wrap (guided sampling:
+                          // both halves of the doubled batch share down1.conv1's output; one image per tile only)
   // init_conv folded into this conv's staging (KIND 0, down1.conv1): when init_x != null the input
   // tile is COMPUTED from the NCHW image (3x3 conv, init_cin -> C1 channels) instead of loaded
   const float* init_x;    // [B, init_cin, H, W]
@@ -456,7 +458,8 @@ __device__ __forceinline__ void gn_tables(const ConvArgs& p, int step, int img0,
     const int n = img0 + i;
     float scale = 0.f, shift = 0.f, tv = 0.f;
     if (p.ni == 1 || n < p.B) {  // (one image per tile: the grid covers exactly B images)
-      const float* st = p.stats_in + ((size_t)n * p.pin * DM_GROUPS + (c >> p.g1_log)) * 2;
+      const int nsrc = (p.in_wrap && n >= p.in_wrap) ? n - p.in_wrap : n;  // (the time embedding below is the image's own)
+      const float* st = p.stats_in + ((size_t)nsrc * p.pin * DM_GROUPS + (c >> p.g1_log)) * 2;
       float msum = 0.f, mean, m2 = 0.f, dev = 0.f;
       if (p.pin <= 8) {  // the usual case: all partials in ONE round of independent 8-byte loads, same arithmetic
         float2 pr[8];
@@ -788,7 +791,8 @@ __global__ __launch_bounds__(256, KIND == 5 ? 2 : 3) void conv_mfma_kernel(const
     } else if constexpr (WINO) {
       const int c4 = tq & 15;
       const int cs_log = from2 ? p.c2_log : p.c1_log;
-      const float* srcb = src + ((size_t)img0 << (p.h_log + p.w_log + cs_log)) + coff + c4 * 4;
+      const int simg = (p.in_wrap && img0 >= p.in_wrap) ? img0 - p.in_wrap : img0;
+      const float* srcb = src + ((size_t)simg << (p.h_log + p.w_log + cs_log)) + coff + c4 * 4;
       const int imax = p.B - 1 - img0;  // images past the batch: clamped address, zero fill
       const int hw1 = (p.H << p.w_log) - 1;
       float4 v[UW];

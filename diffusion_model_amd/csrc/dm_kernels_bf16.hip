@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
     int tq = threadIdx.x;  // opaque copy: the index math below is redone per call, not hoisted and kept live (spilled)
     asm volatile("" : "+v"(tq));
     // 64-bit base of this tile's first image + 32-bit offsets inside the tile's image group
-    const bf16_t* srcb = src + ((size_t)a.img0 << (p.h_log + p.w_log + cs_log)) + coff;
+    const int simg = (p.in_wrap && a.img0 >= p.in_wrap) ? a.img0 - p.in_wrap : a.img0;
+    const bf16_t* srcb = src + ((size_t)simg << (p.h_log + p.w_log + cs_log)) + coff;
     inbm = 0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
