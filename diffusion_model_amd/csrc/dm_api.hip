@@ -217,7 +217,7 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   const int cin = c.c1 + c.c2;
   int kind = c.kind == 6 ? 1 : c.kind;
   if (kind != 0 && kind != 1 && kind != 2) return fail("conv (split-bf16): kind %d is not 3x3 / 4x4 stride 2 / transposed 4x4", c.kind);
-  if (c.res || c.init_x) return fail("conv (split-bf16): no residual / folded init_conv variant");
+  if (c.res || c.init_x || c.in_wrap) return fail("conv (split-bf16): no residual / folded init_conv / shared-input variant");
   if (c.c1 % 64 || c.c2 % 64 || c.cout % 64 || !is_pow2(c.c1) || (c.c2 && !is_pow2(c.c2)) || !is_pow2(c.cout))
     return fail("conv (split-bf16): channel counts must be powers of two >= 64 (got %d+%d -> %d)", c.c1, c.c2, c.cout);
   if (!is_pow2(c.H) || !is_pow2(c.W)) return fail("conv: spatial dims must be powers of two (got %dx%d)", c.H, c.W);

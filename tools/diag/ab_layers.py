@@ -5,7 +5,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import torch
     from diffusion_model_amd import _lib
     L = _lib.lib(); dev = 'cuda'
-    def run(kind, H, B=1024, c2=0, reps=40):
+    def run(kind, H, B=int(os.environ.get('AB_B', 1024)), c2=0, reps=40):
         base = {5: 0, 7: 0, 6: 1, 8: 1, 9: 2}.get(kind, kind); ks = 3 if base == 0 else 4
         OH = H // 2 if base == 1 else 2 * H if base == 2 else H
         x1 = torch.randn(B, H, H, 64, device=dev); x2 = torch.randn(B, H, H, 64, device=dev) if c2 else None
