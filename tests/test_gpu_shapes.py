@@ -1,0 +1,45 @@
+"""Non-square images (the reference's forward takes any H, W divisible by 8; model.py:120-151): every kernel's
+tile geometry with H != W, against the CPU oracle, plus batch independence and a short sampling chain."""
+import pytest
+import torch
+
+import diffusion_model_amd as d
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+EPS_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def sd():
+    d.set_seed(42)
+    m = d.UNetMini(image_size=32).eval()
+    return {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("H,W,B", [(32, 64, 3), (64, 32, 3), (16, 32, 5), (32, 16, 5), (8, 16, 4), (16, 8, 4), (8, 32, 2),
+                                   (64, 16, 2), (32, 128, 1), (128, 32, 1)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_forward_non_square(sd, H, W, B, precision):
+    m = d.UNetMini(image_size=max(H, W), precision=precision).eval()
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    x = torch.randn((B, 1, H, W), generator=g)
+    t = torch.tensor(417)
+    if precision == "bf16" and min(H, W) < 16:
+        with pytest.raises(RuntimeError, match=">= 16"):
+            m(x.to(DEV), t)
+        return
+    with torch.no_grad():
+        ref = O.unet_forward(sd, x, t)
+    full = m(x.to(DEV), t)
+    err = (full.cpu() - ref).abs().max().item()
+    assert err <= (EPS_TOL if precision == "fp32" else 2e-2), err
+    assert torch.equal(full, m(x.to(DEV), t))
+    if B > 1:
+        assert torch.equal(m(x[B - 1:].contiguous().to(DEV), t), full[B - 1:])
+    smp = d.DDIMSampler(d.DDPMScheduler(), num_inference_steps=5, eta=0.0)
+    out = smp.sample_from(m, x).cpu()
+    refs = O.sample(sd, O.make_schedule(), x.shape, 5, 0.0, x_T=x)
+    assert (out - refs).abs().max().item() <= (1e-3 if precision == "fp32" else 1e-1)
