@@ -208,8 +208,10 @@ class UNetMini(nn.Module):
                     t, nt = t.expand(B).contiguous(), B
                 else:
                     raise RuntimeError(f"cond_emb must be [{nt},{self.time_emb_dim}]")
-        ws = self.workspace(B, H, W)
         eps = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=dev)
+        if B == 0:  # the reference's stock ops return an empty [0, Cout, H, W] tensor
+            return eps
+        ws = self.workspace(B, H, W)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().dm_unet_forward(
                 self._native(), _lib.ptr(packed), _lib.ptr(x), _lib.ptr(t), nt, _lib.ptr(cond), _lib.ptr(eps),

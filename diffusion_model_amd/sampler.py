@@ -68,6 +68,8 @@ class _SamplerBase:
         B, Cin, H, W = x_T.shape
         n = timesteps.numel()
         x = x_T.to(dev, torch.float32).contiguous().clone()
+        if B == 0:  # the reference loops over an empty batch and returns it
+            return x
         # device copies of the timestep list and the per-step coefficient table, kept across calls (they depend on
         # the scheduler tables, the timesteps and eta only): a pageable H2D copy is a host-side sync point per pass
         src = getattr(self, "_dev_tables_src", None)  # (identity + version of the source tensors: no D2H read-back)

@@ -109,6 +109,8 @@ class DDPMScheduler:
             nz = nz.to(x.device, torch.float32).contiguous()
         out = torch.empty_like(x)
         n = x.numel()
+        if n == 0:  # empty batch: the reference's elementwise ops return an empty tensor
+            return out
         if n % 4:
             raise RuntimeError("element count must be a multiple of 4")
         cbuf = (C.c_float * 5)(*[float(v) for v in coef[:5]])
@@ -123,6 +125,8 @@ class DDPMScheduler:
         x = sample.contiguous()
         e = model_output.contiguous()
         B = x.shape[0]
+        if B == 0 and timestep.numel() == 0:
+            return torch.empty_like(x)
         if timestep.numel() != B:
             raise RuntimeError(f"timestep must have 1 or {B} elements, got {timestep.numel()}")
         if x.dtype != torch.float32 or e.dtype != torch.float32 or x.shape != e.shape or x.device != e.device:

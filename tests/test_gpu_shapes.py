@@ -43,3 +43,16 @@ def test_forward_non_square(sd, H, W, B, precision):
     out = smp.sample_from(m, x).cpu()
     refs = O.sample(sd, O.make_schedule(), x.shape, 5, 0.0, x_T=x)
     assert (out - refs).abs().max().item() <= (1e-3 if precision == "fp32" else 1e-1)
+
+
+def test_empty_batch(sd):
+    """B = 0: the reference's stock ops return empty tensors (forward, both sampler loops, scheduler.step)."""
+    m = d.UNetMini(image_size=32).eval()
+    m.load_state_dict(sd)
+    x = torch.zeros((0, 1, 32, 32), device=DEV)
+    assert m(x, torch.tensor(5)).shape == (0, 1, 32, 32)
+    sched = d.DDPMScheduler()
+    assert d.DDIMSampler(sched, num_inference_steps=5).sample_from(m, x.cpu()).shape == (0, 1, 32, 32)
+    assert d.AncestralSampler(sched, num_inference_steps=10)(m, (0, 1, 32, 32), progress_bar=False).shape == (0, 1, 32, 32)
+    assert sched.step(x, 3, x).shape == (0, 1, 32, 32)
+    assert sched.step(x, torch.zeros(0, dtype=torch.int64), x).shape == (0, 1, 32, 32)
