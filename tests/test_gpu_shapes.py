@@ -56,3 +56,32 @@ def test_empty_batch(sd):
     assert d.AncestralSampler(sched, num_inference_steps=10)(m, (0, 1, 32, 32), progress_bar=False).shape == (0, 1, 32, 32)
     assert sched.step(x, 3, x).shape == (0, 1, 32, 32)
     assert sched.step(x, torch.zeros(0, dtype=torch.int64), x).shape == (0, 1, 32, 32)
+
+
+def test_noise_staging_three_chunks_host_and_device_noise(sd):
+    """dm_sample stages the per-step noise 50 steps at a time: n = 130 is three chunks (50, 50, 30).  Pageable, pinned and
+    device noise, graph and eager, must equal the step-by-step loop (model(x, t) + scheduler.step: no staging at all) bit
+    for bit; a second call with other noise right behind the first must not see the first call's chunks."""
+    m = d.UNetMini(image_size=32).eval()
+    m.load_state_dict(sd)
+    sched = d.DDPMScheduler()
+    smp = d.AncestralSampler(sched, num_inference_steps=130, eta=1.0)
+    n = sched.timesteps.numel()
+    assert n > 100
+    g = torch.Generator().manual_seed(5)
+    x_T = torch.randn((3, 1, 32, 32), generator=g)
+    nz_a = torch.randn((n, 3, 1, 32, 32), generator=g)
+    nz_b = torch.randn((n, 3, 1, 32, 32), generator=g)
+
+    def loop(nz):  # any callable that is not a UNetMini is driven step by step
+        return smp.sample_from(lambda x, t: m(x, t), x_T, nz)
+
+    ref_a, ref_b = loop(nz_a), loop(nz_b)
+    assert not torch.equal(ref_a, ref_b)
+    for use_graph in (True, False):
+        smp.use_graph = use_graph
+        for src in (nz_a, nz_a.pin_memory(), nz_a.to(DEV)):
+            assert torch.equal(smp.sample_from(m, x_T, src), ref_a), (use_graph, src.device, src.is_pinned())
+        a = smp.sample_from(m, x_T, nz_a.pin_memory())
+        b = smp.sample_from(m, x_T, nz_b.pin_memory())  # enqueued behind a: the staging area is rewritten only after a's steps
+        assert torch.equal(a, ref_a) and torch.equal(b, ref_b), use_graph
