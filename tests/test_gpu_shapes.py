@@ -85,3 +85,21 @@ def test_noise_staging_three_chunks_host_and_device_noise(sd):
         a = smp.sample_from(m, x_T, nz_a.pin_memory())
         b = smp.sample_from(m, x_T, nz_b.pin_memory())  # enqueued behind a: the staging area is rewritten only after a's steps
         assert torch.equal(a, ref_a) and torch.equal(b, ref_b), use_graph
+
+
+def test_full_size_shard_ddim50_rows_bit_identical_and_match_oracle(sd):
+    """BASELINE configs[2] at the size of one GPU's shard (8,192 images, DDIM-50): what each of 8 ranks of a 1,024-image
+    sharding would compute alone equals the same rows of the 8,192-image run bit for bit (size-independent property of
+    the sharded path), and a few rows agree with the CPU oracle after 50 free-running steps."""
+    m = d.UNetMini(image_size=32).eval()
+    m.load_state_dict(sd)
+    smp = d.DDIMSampler(d.DDPMScheduler(), num_inference_steps=50, eta=0.0)
+    g = torch.Generator().manual_seed(8192)
+    x_T = torch.randn((8192, 1, 32, 32), generator=g)
+    full = smp.sample_from(m, x_T)
+    assert torch.isfinite(full).all()
+    for lo in (0, 3072, 7168):
+        part = smp.sample_from(m, x_T[lo:lo + 1024].contiguous())
+        assert torch.equal(part, full[lo:lo + 1024]), lo
+    ref = O.sample(sd, O.make_schedule(), (4, 1, 32, 32), 50, 0.0, x_T=x_T[8188:])
+    assert (full[8188:].cpu() - ref).abs().max().item() <= 1e-3
