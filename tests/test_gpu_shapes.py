@@ -103,3 +103,64 @@ def test_full_size_shard_ddim50_rows_bit_identical_and_match_oracle(sd):
         assert torch.equal(part, full[lo:lo + 1024]), lo
     ref = O.sample(sd, O.make_schedule(), (4, 1, 32, 32), 50, 0.0, x_T=x_T[8188:])
     assert (full[8188:].cpu() - ref).abs().max().item() <= 1e-3
+
+
+def test_results_do_not_depend_on_kernels_of_other_streams(sd):
+    """A model forward and a sampling chain must give the same bits whether or not another stream keeps the matrix pipe busy.
+    (Found with two sampling chains on two streams: packed fp32 instructions whose low result half reads the high half of a
+    source - written by hand in init5_kernel, and generated by hipcc's SLP vectoriser elsewhere - returned wrong low halves
+    in lanes 48-63 while a bf16-MFMA kernel of another stream shared the SIMD: 35 of 40 forwards differed.  The library now
+    contains no such instruction.)  The co-runner is the library's own split-bf16 transposed conv, launched back to back."""
+    import torch.nn.functional as F  # noqa: F401
+    from diffusion_model_amd import _lib
+    from tests.test_gpu_kernels import pack
+    L = _lib.lib()
+    m = d.UNetMini(image_size=32).eval()
+    m.load_state_dict(sd)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((32, 1, 32, 32), generator=g).to(DEV)
+    t = torch.tensor(321)
+    # co-runner: ConvTranspose2d 4x4 s2 on the bf16 pipe (kind 9), 16x16 -> 32x32, B = 32
+    xa = torch.randn(32, 16, 16, 64, device=DEV)
+    wa = torch.randn(64, 64, 4, 4) * 0.05
+    wp = torch.empty(L.dm_conv_packed_floats(9, 64, 64), device=DEV)
+    wd = wa.to(DEV)
+    _lib.check(L.dm_pack_conv_weight(9, _lib.ptr(wd), 64, 64, _lib.ptr(wp), torch.cuda.current_stream().cuda_stream))
+    ba = torch.zeros(64, device=DEV)
+    ya = torch.empty(32, 32, 32, 64, device=DEV)
+    torch.cuda.synchronize()
+
+    def co_run(reps):
+        for _ in range(reps):
+            _lib.check(L.dm_conv2d(9, _lib.ptr(xa), 64, None, 0, _lib.ptr(wp), _lib.ptr(ba), 64, None, 0, 0.0, None, None, None, 0,
+                                   _lib.ptr(ya), None, 32, 16, 16, s2.cuda_stream))
+
+    with torch.cuda.stream(s1):
+        ref = m(x, t)
+    torch.cuda.synchronize()
+    for trial in range(20):
+        co_run(30)
+        with torch.cuda.stream(s1):
+            out = m(x, t)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), trial
+    # two sampling chains at once (each on its own stream and model instance) == each alone
+    import diffusion_model_amd.sampler as sampler_mod
+    m2 = d.UNetMini(image_size=32).eval()
+    m2.load_state_dict(sd)
+    smps = [d.DDIMSampler(d.DDPMScheduler(), num_inference_steps=20, eta=0.0) for _ in range(2)]
+    xs = [torch.randn((16, 1, 32, 32), generator=g) for _ in range(2)]
+    alone = [smps[c].sample_from(mm, xs[c]) for c, mm in enumerate((m, m2))]
+    torch.cuda.synchronize()
+    saved = sampler_mod._side_stream
+    try:
+        outs = []
+        for c, mm in enumerate((m, m2)):
+            sampler_mod._side_stream = lambda dev, c=c: (s1, s2)[c]
+            with torch.cuda.stream((s1, s2)[c]):
+                outs.append(smps[c].sample_from(mm, xs[c]))
+        torch.cuda.synchronize()
+    finally:
+        sampler_mod._side_stream = saved
+    assert torch.equal(outs[0], alone[0]) and torch.equal(outs[1], alone[1])
