@@ -136,15 +136,21 @@ def test_results_do_not_depend_on_kernels_of_other_streams(sd):
             _lib.check(L.dm_conv2d(9, _lib.ptr(xa), 64, None, 0, _lib.ptr(wp), _lib.ptr(ba), 64, None, 0, 0.0, None, None, None, 0,
                                    _lib.ptr(ya), None, 32, 16, 16, s2.cuda_stream))
 
-    with torch.cuda.stream(s1):
-        ref = m(x, t)
-    torch.cuda.synchronize()
-    for trial in range(20):
-        co_run(30)
+    d.set_seed(7)
+    wide = d.UNetMini(image_size=64, in_channels=3, out_channels=3, model_channels=256, attention=True).eval()
+    mb = d.UNetMini(image_size=32, precision="bf16").eval()
+    mb.load_state_dict(sd)
+    xw = torch.randn((2, 3, 64, 64), generator=g).to(DEV)
+    for name, mm, xx, trials in (("fp32", m, x, 20), ("bf16", mb, x, 10), ("wide + attention", wide, xw, 6)):
         with torch.cuda.stream(s1):
-            out = m(x, t)
+            ref = mm(xx, t)
         torch.cuda.synchronize()
-        assert torch.equal(out, ref), trial
+        for trial in range(trials):
+            co_run(30)
+            with torch.cuda.stream(s1):
+                out = mm(xx, t)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (name, trial)
     # two sampling chains at once (each on its own stream and model instance) == each alone
     import diffusion_model_amd.sampler as sampler_mod
     m2 = d.UNetMini(image_size=32).eval()
