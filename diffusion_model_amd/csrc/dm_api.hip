@@ -671,7 +671,7 @@ int attention_block(const dm_unet* m, const float* P, int which, float* X, const
 size_t init5_lds(const dm_unet* m, int H, int W) {
   if (H < 16 || W < 16 || H % 8 || W % 16) return 0;      // (H >= 16: a tile position has at most one special row class)
   const int sets = 2 * (W == 16 ? 3 : 2);
-  const size_t f = (size_t)((2 * m->Cin * 240 + 3) & ~3) + (size_t)sets * (25 * m->Cin + 1) * 64 + 72;  // patch (every value twice) + weight sets + reduction words
+  const size_t f = (size_t)((m->Cin * 240 + 3) & ~3) + (size_t)sets * (25 * m->Cin + 1) * 64 + 72;  // patch + weight sets + reduction words
   return f * sizeof(float) <= 150 * 1024 ? f * sizeof(float) : 0;
 }
 

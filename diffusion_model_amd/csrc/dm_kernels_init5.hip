@@ -18,13 +18,20 @@
 #pragma once
 #include "dm_kernels.hip"
 
-// acc.xy += w.xy * (x, x): a PLAIN v_pk_fma_f32 on a pair that holds the image value twice (the LDS patch stores every value
-// twice, so one ds_read_b64 delivers the pair).  No op_sel: measured on gfx950 (tools/diag/corun_forward.py), v_pk_fma_f32 with
+// acc.xy += w.xy * (x, x): a PLAIN v_pk_fma_f32 on a pair that holds the image value twice (one ds_read2_b32 with both offsets
+// equal delivers it).  No op_sel: measured on gfx950 (tools/diag/corun_forward.py), v_pk_fma_f32 with
 // op_sel:[0,1,0] (low half of the result from the HIGH half of src1) returns the low half computed from src1's LOW half in lanes
 // 48-63 now and then while ANOTHER wave of the SIMD streams bf16 MFMAs - i.e. whenever a split-bf16 kernel of another stream
 // shares the CU.  Plain packed FMAs, like scalar ones, are not affected.
 typedef float i5_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void i5_fma(i5_f2& acc, i5_f2 w, i5_f2 xx) { acc = __builtin_elementwise_fma(w, xx, acc); }
+// (v, v) from ONE LDS word: ds_read2_b32 with both offsets equal (offsets in dwords, 0..255).  hipcc does not track the LDS
+// counter of inline asm: the reads of a column are followed by i5_lds_wait, which also ties the values to the wait.
+#define I5_LDS_PAIR(dst, addr, off) asm volatile("ds_read2_b32 %0, %1 offset0:" #off " offset1:" #off : "=v"(dst) : "v"(addr))
+__device__ __forceinline__ void i5_lds_wait(i5_f2 (&x)[12]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+               "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
+}
 
 struct Init5Args {
   const float* x;        // [B, Cin, H, W]
@@ -52,8 +59,8 @@ __global__ __launch_bounds__(256, 3) void init5_kernel(const Init5Args p) {
   const int rsp = (y0 == 0) ? 1 : (y0 + 8 == p.H) ? 2 : 0;          // this position's special row class (H >= 16: at most one)
   const bool cl = x0 == 0, cr = x0 + 16 == p.W;                      // special column classes present
   const int ncs = (cl ? 1 : 0) + (cr ? 1 : 0);
-  i5_f2* xs = reinterpret_cast<i5_f2*>(smem);                        // [Cin][PH][PW] pairs (v, v)
-  float* ws = smem + ((2 * Cin * PH * PW + 3) & ~3);                 // [(1 + (rsp != 0)) x (1 + ncs)] sets
+  float* xs = smem;                                                  // [Cin][PH][PW]
+  float* ws = xs + ((Cin * PH * PW + 3) & ~3);                       // [(1 + (rsp != 0)) x (1 + ncs)] sets
   // local set index: lr * (1 + ncs) + lc;  lc: 0 interior, then left (if present), then right (if present)
   for (int lr = 0; lr < (rsp ? 2 : 1); ++lr)
     for (int lc = 0; lc <= ncs; ++lc) {
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256, 3) void init5_kernel(const Init5Args p) {
     __syncthreads();  // previous image's readers of xs are done (first pass: the weight sets are in LDS)
 #pragma unroll
     for (int q = 0; q < NPF; ++q)
-      if (tid + q * 256 < Cin * PH * PW) xs[tid + q * 256] = i5_f2{pf[q], pf[q]};
+      if (tid + q * 256 < Cin * PH * PW) xs[tid + q * 256] = pf[q];
     __syncthreads();
     fetch(n + n_step);
     // (opaque copies: the weights are read from LDS per image; hoisted out of the image loop they would take 200 registers)
@@ -113,8 +120,12 @@ __global__ __launch_bounds__(256, 3) void init5_kernel(const Init5Args p) {
 #pragma unroll 1
       for (int dx = 0; dx < 5; ++dx) {  // (rolled: unrolled, hipcc loads several columns ahead and spills 165 registers)
         i5_f2 xr[PH];  // column col + dx of the patch, rows 0..11, every value as a pair (v, v)
-#pragma unroll
-        for (int r = 0; r < PH; ++r) xr[r] = xs[(ci * PH + r) * PW + col + dx];
+        static_assert(PH == 12 && PW == 20, "row offsets below");
+        const unsigned xa = (unsigned)(unsigned long long)(xs + ci * PH * PW + col + dx);  // (LDS aperture: the low 32 bits are the LDS address)
+        I5_LDS_PAIR(xr[0], xa, 0); I5_LDS_PAIR(xr[1], xa, 20); I5_LDS_PAIR(xr[2], xa, 40); I5_LDS_PAIR(xr[3], xa, 60);
+        I5_LDS_PAIR(xr[4], xa, 80); I5_LDS_PAIR(xr[5], xa, 100); I5_LDS_PAIR(xr[6], xa, 120); I5_LDS_PAIR(xr[7], xa, 140);
+        I5_LDS_PAIR(xr[8], xa, 160); I5_LDS_PAIR(xr[9], xa, 180); I5_LDS_PAIR(xr[10], xa, 200); I5_LDS_PAIR(xr[11], xa, 220);
+        i5_lds_wait(xr);
 #pragma unroll
         for (int dy = 0; dy < 5; ++dy) {
           const float4 w = *reinterpret_cast<const float4*>(wi + ((ci * 25 + dy * 5 + dx) * 64) + c4 * 4);
