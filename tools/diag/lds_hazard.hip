@@ -8,6 +8,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 __global__ __launch_bounds__(256, 2) void burner(int iters, float* sink) {
+  extern __shared__ float burner_lds[];  // 64 KB of dynamic LDS: at most two burner workgroups per CU, so the kernel under test is co-resident
+  if (iters < 0) burner_lds[threadIdx.x] = 0.f;
   f32x16 acc[4]; for (int q = 0; q < 4; ++q) for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
   bf16x8 a = __builtin_bit_cast(bf16x8, make_float4(1.37f * threadIdx.x, 0.11f, 3.3f, 0.7f)), b = __builtin_bit_cast(bf16x8, make_float4(0.37f, 2.11f, 1.3f, 0.9f));
   for (int it = 0; it < iters; ++it)
@@ -83,7 +85,7 @@ template <int MODE> void run(const char* name, hipStream_t s1, hipStream_t s2, u
   for (int co = 0; co < 2; ++co) {
     CK(hipMemset(bad, 0, 16));
     CK(hipDeviceSynchronize());
-    if (co == 1) hipLaunchKernelGGL(burner, dim3(2048), dim3(256), 0, s2, 3000, sink);
+    if (co == 1) hipLaunchKernelGGL(burner, dim3(2048), dim3(256), 64 * 1024, s2, 3000, sink);
     for (int rep = 0; rep < 10; ++rep) hipLaunchKernelGGL(test<MODE>, dim3(1024), dim3(256), 32768, s1, 2000, bad);
     CK(hipDeviceSynchronize());
     unsigned h[4]; CK(hipMemcpy(h, bad, 16, hipMemcpyDeviceToHost));
@@ -91,6 +93,7 @@ template <int MODE> void run(const char* name, hipStream_t s1, hipStream_t s2, u
   }
 }
 int main() {
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&burner), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
   unsigned* bad; float* sink; CK(hipMalloc(&bad, 16)); CK(hipMalloc(&sink, 16));
   run<0>("ds_read_b128 checked", s1, s2, bad, sink);
