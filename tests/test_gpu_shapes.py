@@ -170,3 +170,25 @@ def test_results_do_not_depend_on_kernels_of_other_streams(sd):
     finally:
         sampler_mod._side_stream = saved
     assert torch.equal(outs[0], alone[0]) and torch.equal(outs[1], alone[1])
+
+
+def test_batch_65536_on_one_gpu_crosses_the_32_bit_element_boundary(sd):
+    """BASELINE configs[2] unsharded: 65,536 images on ONE GPU are 4.3e9 activation elements per full-resolution layer
+    (past 2^32; 60 GiB of workspace).  Rows at the start, on both sides of the boundary and at the end equal the same rows
+    sampled in a batch of 16."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2**30:
+        pytest.skip("needs 80 GiB of free device memory")
+    m = d.UNetMini(image_size=32).eval()
+    m.load_state_dict(sd)
+    smp = d.DDIMSampler(d.DDPMScheduler(), num_inference_steps=4, eta=0.0)
+    B = 65536
+    g = torch.Generator().manual_seed(7)
+    x_T = torch.randn((B, 1, 32, 32), generator=g)
+    full = smp.sample_from(m, x_T)
+    assert torch.isfinite(full).all()
+    for lo in (0, B // 2 - 8, B // 2, B - 16):
+        assert torch.equal(smp.sample_from(m, x_T[lo:lo + 16].contiguous()), full[lo:lo + 16]), lo
+    m._ws = None
+    del full
+    torch.cuda.empty_cache()
