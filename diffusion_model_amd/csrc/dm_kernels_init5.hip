@@ -27,7 +27,7 @@ typedef float i5_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void i5_fma(i5_f2& acc, i5_f2 w, i5_f2 xx) { acc = __builtin_elementwise_fma(w, xx, acc); }
 // (v, v) from ONE LDS word: ds_read2_b32 with both offsets equal (offsets in dwords, 0..255).  hipcc does not track the LDS
 // counter of inline asm: the reads of a column are followed by i5_lds_wait, which also ties the values to the wait.
-#define I5_LDS_PAIR(dst, addr, off) asm volatile("ds_read2_b32 %0, %1 offset0:" #off " offset1:" #off : "=v"(dst) : "v"(addr))
+#define I5_LDS_PAIR(dst, addr, off) asm volatile("ds_read2_b32 %0, %1 offset0:" #off " offset1:" #off : "=v"(dst) : "v"(addr) : "memory")
 __device__ __forceinline__ void i5_lds_wait(i5_f2 (&x)[12]) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
                "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
