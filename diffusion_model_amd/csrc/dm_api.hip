@@ -691,7 +691,7 @@ int launch_init5(const dm_unet* m, const float* P, const float* x, float* y, flo
     attr_done[dev] = true;
   }
   // workgroups keep one tile position: grid.x = tiles_per_img x (images walked in parallel)
-  const unsigned per_cu = lds > 80 * 1024 ? 1u : lds > 53 * 1024 ? 2u : 3u;  // (168 registers: three waves per SIMD)
+  const unsigned per_cu = lds > 80 * 1024 ? 1u : lds > 53 * 1024 ? 2u : 3u;  // (142 registers: three waves per SIMD)
   unsigned par = per_cu * cu_count(dev) / (unsigned)(a.tiles_per_img * (m->C / 64));
   if (par < 1) par = 1;
   if (par > (unsigned)B) par = (unsigned)B;
