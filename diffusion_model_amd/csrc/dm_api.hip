@@ -560,9 +560,9 @@ int check_geometry(const dm_unet* m, int B, int H, int W) {
 
 int launch_time_embed(const dm_unet* m, const float* P, const int64_t* t, int nt, const float* cond,
                       float* temb, float* heads, hipStream_t s, const int* step_ptr = nullptr, int step_off = 0,
-                      int t_stride = 1) {
+                      int t_stride = 1, const float* temb_in = nullptr) {
   TimeArgs a;
-  a.step_ptr = step_ptr; a.step_off = step_off; a.t_stride = t_stride;
+  a.step_ptr = step_ptr; a.step_off = step_off; a.t_stride = t_stride; a.temb_in = temb_in;
   a.freqs = P + m->o_freqs;
   a.w1 = P + m->o_tm1w; a.b1 = P + m->o_tm1b; a.w2 = P + m->o_tm2w; a.b2 = P + m->o_tm2b;
   for (int k = 0; k < 6; ++k) { a.hw[k] = P + m->blk[k].tmw; a.hb[k] = P + m->blk[k].tmb; }
@@ -1159,6 +1159,8 @@ int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, co
   // Time embeddings of all n steps up front: they depend on t only.  With
   // guidance every image has its own embedding (time + class): computed per step for 2B rows.
   if (!cfg && launch_time_embed(m, packed, w.ts, n, nullptr, nullptr, w.heads, s)) return 1;
+  // (guidance: the time MLP of all n steps once - it depends on t only -; per step only the heads of time + class embedding)
+  if (cfg && launch_time_embed(m, packed, w.ts, n, nullptr, w.temb, w.heads, s)) return 1;
   const int hstep = 6 * m->C;
   float* xc = w.xcur;
 
@@ -1173,7 +1175,8 @@ int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, co
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(dup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xc, w.xx, count);
     HIP_TRY(hipGetLastError());
-    if (launch_time_embed(m, packed, w.ts, Bd, w.cond, nullptr, w.heads, s, step_ptr, step_off, 0)) return 1;
+    static const bool no_table = getenv("DM_DEBUG_NO_TEMB_TABLE") != nullptr;  // diagnostics only: the time MLP per entry and step, as before
+    if (launch_time_embed(m, packed, w.ts, Bd, w.cond, nullptr, w.heads, s, step_ptr, step_off, 0, no_table ? nullptr : w.temb)) return 1;
     if (unet_body(m, packed, w.xx, w.eps, w.heads, hstep, 0, nullptr, 0, w, Bd, H, W, s, B)) return 1;
     return launch_step(xc, w.eps, noise ? w.noise : nullptr, local, w.coefs, step_ptr, step_off, nullptr, xc, count, 1, guidance, s);
   };

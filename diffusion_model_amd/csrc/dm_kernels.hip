@@ -1356,6 +1356,8 @@ struct TimeArgs {
   const int* step_ptr;           // null or device step counter; tbase = *step_ptr + step_off
   int step_off, t_stride;
   const float* cond;             // null or [nt,E]
+  const float* temb_in;          // null, or the time MLP's output per STEP [*, E] (row tbase), computed once up front: entries then are
+                                 // temb_in[tbase] + cond[n] and only the six heads are evaluated (guided sampling: all 2B entries of a step share t)
   float* temb;                   // null or [nt,E]
   float* heads;                  // [nt,6,C]
   int E, C;
@@ -1375,6 +1377,17 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const TimeArgs a, int n
   const int nr = min(R, nt - n0);
   const int half = a.E >> 1;
   const int tbase = (a.step_ptr ? *a.step_ptr : 0) + a.step_off;
+  if (a.temb_in) {  // (uniform) same value and order as below: (W2 h + b2), then + cond
+    for (int idx = threadIdx.x; idx < R * a.E; idx += 256) {
+      const int r = idx / a.E, o = idx - r * a.E;
+      float v = a.temb_in[(size_t)tbase * a.E + o];
+      if (r < nr) {
+        if (a.cond) v += a.cond[(size_t)(n0 + r) * a.E + o];
+        if (a.temb) a.temb[(size_t)(n0 + r) * a.E + o] = v;
+      }
+      te[r * a.E + o] = v;
+    }
+  } else {
   for (int idx = threadIdx.x; idx < nr * half; idx += 256) {
     const int r = idx / half, i = idx - r * half;
     const float tv = (float)a.t[tbase + (size_t)(n0 + r) * a.t_stride];
@@ -1420,6 +1433,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const TimeArgs a, int n
       te[r * a.E + o] = v;
     }
   }
+  }  // !temb_in
   __syncthreads();
   for (int o = threadIdx.x; o < 6 * a.C; o += 256) {
     const int k = o / a.C, c = o - k * a.C;
