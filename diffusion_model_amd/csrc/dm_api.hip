@@ -703,6 +703,21 @@ int launch_init5(const dm_unet* m, const float* P, const float* x, float* y, flo
   return 0;
 }
 
+// Does block 0 run init5_kernel (init_conv composed with down1.conv1) on HxW images, and - guided sampling's doubled batch
+// [x;x] of 2*dup_half images - once for both halves?
+bool uses_init5(const dm_unet* m, int H, int W) {
+  const int x6 = m->bf16 ? 0 : m->x6;
+  if ((x6 & 8) || !m->init5) return false;
+  const bool xs = H * W >= 16 && ((x6 & 4) && (H < 8 || W < 8));
+  const int kd = (!m->bf16 && !xs && H >= 8 && W >= 8) ? 5 : 0;
+  const ConvGeo g1 = conv_geo(kd, H, W, m->C);
+  return !xs && g1.th_log == 3 && g1.tw_log == 4 && g1.ni == 1 && init5_lds(m, H, W) != 0;
+}
+bool shares_first_layers(const dm_unet* m, int B, int H, int W, int dup_half) {
+  static const bool noshare = getenv("DM_DEBUG_NOSHARE") != nullptr;  // diagnostics only
+  return dup_half > 0 && B == 2 * dup_half && !noshare && uses_init5(m, H, W);
+}
+
 // One denoiser evaluation (everything after the time embedding): model.py:135-151.
 // heads: [.., 6, C] table; heads_img_stride = 6*C when every image has its own timestep
 // (training-style [B] t) else 0; in the sampling loop the table is indexed by the step
@@ -758,11 +773,9 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     }
     // down1.conv1 after init_conv: ONE 5x5 convolution from the image where the 3x3 kernel's tiles are 8x16 pixels of one
     // image (so the consumer sees the same GroupNorm partial geometry)
-    const ConvGeo g1 = conv_geo(kd, h, ww, C);
     bool shared1 = false;  // conv1's output holds dup_half images only
-    if (k == 0 && fold_init && m->init5 && !xs && g1.th_log == 3 && g1.tw_log == 4 && g1.ni == 1 && init5_lds(m, h, ww)) {
-      static const bool noshare = getenv("DM_DEBUG_NOSHARE") != nullptr;  // diagnostics only
-      shared1 = dup_half > 0 && B == 2 * dup_half && !noshare;
+    if (k == 0 && uses_init5(m, h, ww)) {
+      shared1 = shares_first_layers(m, B, h, ww, dup_half);
       if (launch_init5(m, P, x, w.T1, w.SA, shared1 ? dup_half : B, h, ww, s)) return 1;
     } else if (launch_conv(c, s)) return 1;
     base(kd, w.T1, C, nullptr, 0, xs ? o.c2x : kd == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
@@ -1171,13 +1184,17 @@ int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, co
       return launch_step(xc, w.eps, noise ? w.noise : nullptr, local, w.coefs, step_ptr, step_off, nullptr, xc, count, 0, 0.f, s);
     }
     // doubled batch [x;x] with embeddings [cond ; null] (build-defined CFG)
-    size_t blocks = (count + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(dup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xc, w.xx, count);
-    HIP_TRY(hipGetLastError());
+    // (when block 0 is evaluated once for both halves, only x itself is read: no duplicate needed)
+    const bool shared = shares_first_layers(m, Bd, H, W, B);
+    if (!shared) {
+      size_t blocks = (count + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(dup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xc, w.xx, count);
+      HIP_TRY(hipGetLastError());
+    }
     static const bool no_table = getenv("DM_DEBUG_NO_TEMB_TABLE") != nullptr;  // diagnostics only: the time MLP per entry and step, as before
     if (launch_time_embed(m, packed, w.ts, Bd, w.cond, nullptr, w.heads, s, step_ptr, step_off, 0, no_table ? nullptr : w.temb)) return 1;
-    if (unet_body(m, packed, w.xx, w.eps, w.heads, hstep, 0, nullptr, 0, w, Bd, H, W, s, B)) return 1;
+    if (unet_body(m, packed, shared ? xc : w.xx, w.eps, w.heads, hstep, 0, nullptr, 0, w, Bd, H, W, s, B)) return 1;
     return launch_step(xc, w.eps, noise ? w.noise : nullptr, local, w.coefs, step_ptr, step_off, nullptr, xc, count, 1, guidance, s);
   };
   // noise of steps [first, first + cnt) -> staging area (noise: [n][count], device or host memory)
