@@ -192,3 +192,23 @@ def test_batch_65536_on_one_gpu_crosses_the_32_bit_element_boundary(sd):
     m._ws = None
     del full
     torch.cuda.empty_cache()
+
+
+def test_guided_sampling_on_the_widened_model():
+    """Classifier-free guidance (build-defined) with C = 256, 64x64x3: the first layers are evaluated once for both halves of the
+    doubled batch through four 64-channel output tiles (ConvArgs.in_wrap with grid.y = 4); against the CPU restatement."""
+    from tests.test_gpu_parity import _conditioner
+    cc, cd = _conditioner()
+    d.set_seed(7)
+    m = d.UNetMini(image_size=64, in_channels=3, out_channels=3, model_channels=256).eval()
+    sdw = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    B, n, w = 2, 3, 3.0
+    g = torch.Generator().manual_seed(31)
+    x_T = torch.randn((B, 3, 64, 64), generator=g)
+    lab = torch.tensor([4, 8])
+    smp = d.DDIMSampler(d.DDPMScheduler(), num_inference_steps=n, eta=0.0)
+    ref = O.cfg_sample(sdw, cd, O.make_schedule(), x_T, lab, 10, w, n)
+    for use_graph in (False, True):
+        smp.use_graph = use_graph
+        out = smp.sample_from(m, x_T, cond_emb=cc(lab), null_emb=cc(torch.tensor([10])), guidance_scale=w).cpu()
+        assert (out - ref).abs().max().item() <= 1e-3, use_graph
