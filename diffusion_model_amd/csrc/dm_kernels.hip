@@ -1213,6 +1213,16 @@ __global__ __launch_bounds__(256) void init_conv_kernel(const float* __restrict_
   }
 }
 
+// Sum over the 16 lanes of a DPP row, in every lane, without the LDS crossbar (ds_bpermute): quad_perm [1,0,3,2], quad_perm
+// [2,3,0,1], row_half_mirror, row_mirror.  (__shfl_xor compiles to ds_bpermute_b32: one LDS instruction per step and value.)
+__device__ __forceinline__ float dm_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------
 // final_conv (model.py:111-115,151): GroupNorm(8) -> SiLU -> Conv2d 1x1 (C -> Cout <= 4), NHWC in,
 // NCHW out.  One pass over the activation: bound by the HBM read of u3 (4*C bytes per pixel).
@@ -1299,7 +1309,7 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
         for (int co = 0; co < 4; ++co) {
           if (co < Cout) {
             float sm = v.x * wv[co].x + v.y * wv[co].y + v.z * wv[co].z + v.w * wv[co].w;
-            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            sm = dm_row16_sum(sm);  // the pixel's 16 lanes are one DPP row
             if (q == 0) out[((size_t)n * Cout + co) * HW + pixb + sl * 64 + p0 + 16 * k] = sm + bias[co];
           }
         }
