@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void final_conv_bf16_kernel(const bf16_t* __re
         for (int co = 0; co < 4; ++co) {
           if (co < Cout) {
             float sm = v.x * wv[co].x + v.y * wv[co].y + v.z * wv[co].z + v.w * wv[co].w;
-            for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            sm = dm_row16_sum(sm);  // the pixel's 16 lanes are one DPP row
             if (q == 0) out[((size_t)n * Cout + co) * HW + pixb + sl * 64 + p0 + 16 * k] = sm + bias[co];
           }
         }
