@@ -87,7 +87,9 @@ __device__ __forceinline__ void x6_epilogue_sw(const ConvArgs& p, f32x16 (&acc)[
       for (int q = 0; q < 4; ++q) {
         if (q < ngw) {
           float v = val[q];
-          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+          v += __shfl_xor(v, 32, 64);
+          v += __shfl_xor(v, 16, 64);
+          v = dm_row16_sum(v);  // (DPP row operations: no LDS crossbar for the last four steps)
           if (lane == 0) sred[wave * 4 + q] = v;
         }
       }
