@@ -75,7 +75,7 @@ def profile_model(model, sched, B, H, W, reps=3):
     torch.cuda.synchronize()
     for r in (1, reps):  # first call warms up
         _lib.check(L.dm_unet_profile(model._native(), _lib.ptr(packed), _lib.ptr(xs), _lib.ptr(t_dev), cbuf, B, H, W,
-                                     _lib.ptr(ws), ws.numel(), r, side.cuda_stream, counts, ms, fl, by))
+                                     _lib.ptr(ws), ws.numel(), r, side.cuda_stream, NK, counts, ms, fl, by))
     bf16 = model.precision == "bf16"
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     tot_ms = sum(ms[k] for k in range(NK))
@@ -278,8 +278,16 @@ def main():
     backend = os.environ.get("DM_BENCH_BACKEND", "nccl")
     if os.environ.get("DM_BENCH_ONE_DEVICE"):
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # plumbing rehearsal WITHOUT a GPU (tests/test_distributed_cpu.py): gloo, host tensors, and a stand-in for the sampler
+    # (x -> -x: no denoiser runs, `value` means nothing and the line says so) - exercises the launch contract, the host-side
+    # shard slicing, the gather and the JSON line of the N > 1 path
+    rehearse = bool(os.environ.get("DM_BENCH_REHEARSE_CPU"))
+    if rehearse:
+        backend = "gloo"
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
     force_dist = bool(os.environ.get("DM_BENCH_FORCE_DIST"))  # rehearsal: a 1-rank RCCL communicator + all-gather
     if force_dist and world == 1:
@@ -299,7 +307,6 @@ def main():
             dist.init_process_group(backend)
 
     import diffusion_model_amd as d
-    from diffusion_model_amd import _lib
 
     strong = args.total_images > 0
     if strong and args.total_images % world:
@@ -308,23 +315,28 @@ def main():
     d.set_seed(42)
     IMG, CIN, CH = (32, 1, 64) if args.model == "mnist" else (64, 3, 256)
     flop_img_step = FLOP_PER_IMAGE_STEP if args.model == "mnist" else flop_per_image_step(CH, IMG * IMG, CIN, CIN)
-    model = d.UNetMini(image_size=IMG, in_channels=CIN, out_channels=CIN, model_channels=CH, precision=args.precision,
-                       attention=args.model == "wide-attn").eval()  # random-init weights, reference architecture
     sched = d.DDPMScheduler()
     eta = args.eta if args.eta is not None else (0.0 if args.sampler == "ddim" else 1.0)
     smp = d.create_sampler(args.sampler, sched, num_inference_steps=n, eta=eta)
-    # synthetic x_T: the full [world*B] draw, each rank takes its row slice
-    from diffusion_model_amd.distributed import sample_sharded, sampler_fn
+    # synthetic x_T: the full [world*B] draw (the same on every rank), sliced ON THE HOST: each rank uploads its own rows only
+    # (4 KiB per image - at 65,536 images the full tensor is 256 MiB per rank, the shard 32 MiB at N = 8)
+    from diffusion_model_amd.distributed import gather_shards, shard_rows, sampler_fn
     g = torch.Generator().manual_seed(42)
-    x_T_host = torch.randn((world * B, CIN, IMG, IMG), generator=g)  # same draw on every rank
-    x_T_full = x_T_host.to(dev)
-    x_T = x_T_full[rank * B:(rank + 1) * B]
-    fn = sampler_fn(smp, model)
+    x_T_host = torch.randn((world * B, CIN, IMG, IMG), generator=g)
+    x_T = shard_rows(x_T_host).to(dev)
+    assert x_T.shape[0] == B
+    model = None
+    if rehearse:
+        fn = lambda x, nz: x.neg()
+    else:
+        model = d.UNetMini(image_size=IMG, in_channels=CIN, out_channels=CIN, model_channels=CH, precision=args.precision,
+                           attention=args.model == "wide-attn").eval()  # random-init weights, reference architecture
+        fn = sampler_fn(smp, model)
     nz_local = None
-    if eta > 0:  # per-step noise of this rank's rows, resident in HBM like x_T
+    if eta > 0 and not rehearse:  # per-step noise of this rank's rows, resident in HBM like x_T
         nz_local = torch.randn((n, B, CIN, IMG, IMG), generator=torch.Generator().manual_seed(43 + rank)).to(dev)
         fn = lambda x, nz: smp.sample_from(model, x, nz_local)
-    if args.cfg:  # build-defined guided sampling: labels arange % 10, null class 10, w = 3
+    if args.cfg and not rehearse:  # build-defined guided sampling: labels arange % 10, null class 10, w = 3
         cc = d.ClassConditioner(11, 128)
         cond_full = cc(torch.arange(world * B) % 10)
         null = cc(torch.tensor([10]))
@@ -332,13 +344,15 @@ def main():
                                            guidance_scale=3.0)
 
     def one_pass():
-        # rank r samples rows [r*B, (r+1)*B); one RCCL all-gather of the finished samples
-        return sample_sharded(fn, x_T_full)
+        # rank r samples rows [r*B, (r+1)*B) (resident in HBM); one RCCL all-gather of the finished samples into a
+        # buffer that is allocated once
+        return gather_shards(fn(x_T, None))
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     if force_dist and world == 1:  # the collective sample_sharded issues for N > 1, on a 1-rank communicator
         o1 = one_pass()
@@ -347,6 +361,8 @@ def main():
         torch.cuda.synchronize()
         assert torch.equal(full, o1)
         print("rehearsal: RCCL all_gather_into_tensor ok", file=sys.stderr)
+    if rehearse:
+        assert torch.equal(one_pass(), x_T_host.neg())  # every rank's rows landed where the unsharded job has them
     for _ in range(args.warmup):
         one_pass()
     barrier()
@@ -374,11 +390,17 @@ def main():
                                + (" (BASELINE configs[1])" if default_cfg and not strong else "")
                                + (f" (BASELINE configs[2]: {args.total_images} images sharded over {world} GPUs)" if strong else ""),
                    "images_per_gpu": B, "ddim_steps": n, "guidance": bool(args.cfg), "parallelism": f"dp{world} (batch-sharded, final all-gather)"},
-        "achieved_tflops_whole_path": value * n * flop_img_step / 1e12,
-        "frac_fp32_mfma_peak_whole_path": value * n * flop_img_step / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
+        # ALGORITHMIC direct-conv FLOPs per second, and their ratio to the fp32-MFMA peak: the Winograd layers
+        # execute 4/9 of them and the 4x4 convolutions run on the bf16 pipe, so the ratio may exceed 1 - the executed
+        # fractions per pipe are in `roofline` and `kernels`
+        "achieved_tflops_whole_path_algorithmic": value * n * flop_img_step / 1e12,
+        "frac_fp32_mfma_peak_whole_path_algorithmic": value * n * flop_img_step / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
     }
+    if rehearse:
+        res["rehearsal"] = "CPU plumbing rehearsal (DM_BENCH_REHEARSE_CPU): stand-in sampler, `value` is not a measurement"
+        args.no_roofline = args.no_cpu_baseline = args.no_configs = True
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not rehearse:
         # end to end: x_T uploaded from (pinned) host memory and the finished samples downloaded inside the timed region
         xh = x_T_host.pin_memory()
         oh = torch.empty_like(xh).pin_memory()
@@ -443,7 +465,7 @@ def main():
     if rank == 0 and world == 1 and default_cfg and not strong and not args.no_configs:
         from oracle import unet_oracle as O
         sd32 = {k_: v.detach().cpu() for k_, v in model.state_dict().items()}
-        del out, x_T_full
+        del out
         model._ws = None
         torch.cuda.empty_cache()
         res["configs"] = run_configs(d, O, dev, sd32)

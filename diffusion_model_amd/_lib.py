@@ -17,6 +17,7 @@ _vp, _sz, _i, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
 _SIGS = {
     "dm_last_error": (C.c_char_p, []),
     "dm_version": (_i, []),
+    "dm_build_key": (C.c_char_p, []),
     "dm_unet_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i]),
     "dm_unet_create_ex": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i]),
     "dm_unet_num_params": (_i, [_vp]),
@@ -30,6 +31,7 @@ _SIGS = {
     "dm_sampler_step": (_i, [_vp, _vp, _vp, C.POINTER(_f), _vp, _sz, _vp]),
     "dm_sampler_coefs": (_i, [_vp, _vp, _vp, _i, _vp, _i, _f, _vp]),
     "dm_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _sz, _i, _vp]),
+    "dm_sample_chunked": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _sz, _i, _vp]),
     "dm_sample_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
     "dm_sampler_step_batched": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "dm_attention": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -39,7 +41,7 @@ _SIGS = {
     "dm_unet_forward_noalloc": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "dm_postprocess": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "dm_class_embed": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
-    "dm_unet_profile": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_f), _i, _i, _i, _vp, _sz, _i, _vp,
+    "dm_unet_profile": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_f), _i, _i, _i, _vp, _sz, _i, _vp, _i,
                              C.POINTER(_i), C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dm_conv_packed_floats": (_sz, [_i, _i, _i]),
     "dm_pack_conv_weight": (_i, [_i, _vp, _i, _i, _vp, _vp]),
@@ -48,6 +50,8 @@ _SIGS = {
                        _i, _i, _i, _vp]),
 }
 EXPORTS = tuple(_SIGS)
+ABI_VERSION = 3  # include/dm_sampler.h: DM_ABI_VERSION
+CHUNK_FN = C.CFUNCTYPE(_vp, _vp, _i, _i)  # dm_chunk_fn
 
 
 def lib():
@@ -62,6 +66,9 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
+        if l.dm_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} implements ABI version {l.dm_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                               "(python -c 'import __graft_entry__ as g; g.build()')")
         _lib = l
     return _lib
 

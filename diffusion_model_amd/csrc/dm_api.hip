@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -264,7 +265,8 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   a.ntiles = (int)grid.x;
   {
     static const unsigned slot_div = getenv("DM_DEBUG_SLOT_DIV") ? (unsigned)atoi(getenv("DM_DEBUG_SLOT_DIV")) : 1u;  // diagnostics only
-    const unsigned per_cu = lds > 80 * 1024 ? 1u : (lds <= 53 * 1024 && g.MT == 64 && getenv("DM_DEBUG_X6_2WG") == nullptr) ? 3u : 2u;  // (64-pixel tiles: <= 159 registers)
+    static const bool x6_2wg = getenv("DM_DEBUG_X6_2WG") != nullptr;  // diagnostics only
+    const unsigned per_cu = lds > 80 * 1024 ? 1u : (lds <= 53 * 1024 && g.MT == 64 && !x6_2wg) ? 3u : 2u;  // (64-pixel tiles: <= 159 registers)
     static const unsigned x6_pc = getenv("DM_DEBUG_X6_PER_CU") ? (unsigned)atoi(getenv("DM_DEBUG_X6_PER_CU")) : 0u;  // diagnostics only
     const unsigned slots = (x6_pc && x6_pc < per_cu ? x6_pc : per_cu) * cu_count(current_device()) / (slot_div ? slot_div : 1u);
     const unsigned resident = slots / (grid.y * grid.z) ? slots / (grid.y * grid.z) : 1u;
@@ -276,7 +278,8 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   a.stamps = g_stamps;
 #endif
   // one image per tile: swapped MFMA operands, stores straight from the registers (x6_epilogue_sw)
-  const bool sw = g.ni == 1 && getenv("DM_DEBUG_NOSWAP") == nullptr;
+  static const bool x6_noswap = getenv("DM_DEBUG_NOSWAP") != nullptr;  // diagnostics only
+  const bool sw = g.ni == 1 && !x6_noswap;
 #define DM_X6(MB_, K_) (ns == 2 ? (sw ? launch_conv_x6_t<MB_, K_, true, 2>(a, grid, lds, s) : launch_conv_x6_t<MB_, K_, false, 2>(a, grid, lds, s)) \
                                : (sw ? launch_conv_x6_t<MB_, K_, true>(a, grid, lds, s) : launch_conv_x6_t<MB_, K_, false>(a, grid, lds, s)))
   if (kind == 0) return g.MT == 128 ? DM_X6(2, 0) : DM_X6(1, 0);
@@ -871,12 +874,14 @@ static __device__ __align__(256) unsigned char scratch[DM_NOALLOC_SCRATCH_BYTES]
 
 namespace {
 void* g_scratch_ptr[DM_MAX_DEVICES] = {nullptr};
+std::mutex g_scratch_mu;  // the per-device lookup below may be reached from several host threads at once
 
 // Address of THIS device's copy of `scratch` (looked up once per device, with that device current).
 int noalloc_scratch(void** out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev < 0 || dev >= DM_MAX_DEVICES) return fail("device ordinal %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
   if (!g_scratch_ptr[dev]) {
     void* p = nullptr;
     HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
@@ -917,7 +922,11 @@ int dm_unet_forward_noalloc(dm_unet* m, const float* packed, const float* x, con
 }
 
 const char* dm_last_error(void) { return g_err.c_str(); }
-int dm_version(void) { return 1; }
+int dm_version(void) { return DM_ABI_VERSION; }
+#ifndef DM_BUILD_KEY
+#define DM_BUILD_KEY "unkeyed"
+#endif
+const char* dm_build_key(void) { return DM_BUILD_KEY; }
 
 int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_channels, int time_emb_dim) {
   return dm_unet_create_ex(out, in_channels, out_channels, model_channels, time_emb_dim, 0);
@@ -1152,7 +1161,17 @@ size_t dm_sample_workspace_bytes(const dm_unet* m, int B, int H, int W, int n, i
 int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, const int64_t* ts,
               const float* coefs, int n, const float* noise, const float* cond, float guidance,
               void* ws, size_t ws_bytes, int use_graph, void* stream) {
+  return dm_sample_chunked(m, packed, x, B, H, W, ts, coefs, n, noise, noise ? 1 : 0, nullptr, nullptr, cond, guidance, ws, ws_bytes,
+                           use_graph, stream);
+}
+
+int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, int W, const int64_t* ts,
+                      const float* coefs, int n, const float* noise_all, int with_noise, dm_chunk_fn chunk_fn, void* chunk_user,
+                      const float* cond, float guidance, void* ws, size_t ws_bytes, int use_graph, void* stream) {
   if (!m || !packed || !x || !ts || !coefs || !ws) return fail("dm_sample: null argument");
+  if (with_noise && !noise_all && !chunk_fn) return fail("dm_sample: with_noise needs the noise tensor or a chunk callback");
+  if (!with_noise && noise_all) return fail("dm_sample: a noise tensor was given but with_noise is 0");
+  const bool noise = with_noise != 0;
   if (m->Cin != m->Cout) return fail("sampling needs in_channels == out_channels (got %d, %d)", m->Cin, m->Cout);
   if (check_geometry(m, B, H, W)) return 1;
   if (n <= 0) return fail("dm_sample: number of steps must be positive");
@@ -1198,9 +1217,20 @@ int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, co
     return launch_step(xc, w.eps, noise ? w.noise : nullptr, local, w.coefs, step_ptr, step_off, nullptr, xc, count, 1, guidance, s);
   };
   // noise of steps [first, first + cnt) -> staging area (noise: [n][count], device or host memory)
+  // The chunk callback runs on the calling thread BEFORE the chunk is enqueued (everything before `first` already is): it
+  // is the per-chunk progress tick (sampler.py:65-66 ticks per step) and, when the caller draws the noise chunk by chunk,
+  // the provider of steps [first, first + cnt) - the draw of chunk k+1 then overlaps the GPU's work on chunk k.
   auto stage_noise = [&](int first, int cnt) -> int {
+    const float* src = noise_all ? noise_all + (size_t)first * count : nullptr;
+    if (chunk_fn) {
+      const float* got = chunk_fn(chunk_user, first, cnt);
+      if (noise && !noise_all) {
+        if (!got) return fail("dm_sample: the chunk callback returned no noise for steps [%d, %d)", first, first + cnt);
+        src = got;
+      }
+    }
     if (!noise) return 0;
-    HIP_TRY(hipMemcpyAsync(w.noise, noise + (size_t)first * count, (size_t)cnt * count * sizeof(float), hipMemcpyDefault, s));
+    HIP_TRY(hipMemcpyAsync(w.noise, src, (size_t)cnt * count * sizeof(float), hipMemcpyDefault, s));
     return 0;
   };
 
@@ -1264,9 +1294,10 @@ int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, co
 
 int dm_unet_profile(dm_unet* m, const float* packed, float* x, const int64_t* t_dev, const float* coef_host,
                     int B, int H, int W, void* ws, size_t ws_bytes, int reps, void* stream,
-                    int* counts, float* ms, double* flops, double* bytes) {
+                    int nk, int* counts, float* ms, double* flops, double* bytes) {
   if (!m || !packed || !x || !t_dev || !coef_host || !ws || !counts || !ms || !flops || !bytes)
     return fail("dm_unet_profile: null argument");
+  if (nk != DM_K_COUNT) return fail("dm_unet_profile: the result arrays hold %d entries, this library reports DM_K_COUNT = %d kernel classes", nk, (int)DM_K_COUNT);
   if (check_geometry(m, B, H, W)) return 1;
   if (m->Cin != m->Cout) return fail("dm_unet_profile needs in_channels == out_channels");
   Workspace w = carve(m, ws, B, H, W, 1);

@@ -51,7 +51,8 @@ class _SamplerBase:
                 if null_emb is None:
                     raise RuntimeError("guidance needs null_emb (embedding of the null class)")
                 cond = torch.cat([cond_emb.reshape(B, -1), null_emb.reshape(-1, cond_emb.shape[-1]).expand(B, -1)])
-            return self._fused(model, x_T, noises if self.eta > 0 else None, timesteps, cond, guidance_scale)
+            return self._fused(model, x_T, noises if self.eta > 0 else None, timesteps, cond, guidance_scale,
+                               progress_bar=progress_bar)
         if cond_emb is not None:
             raise RuntimeError("guidance is implemented for this package's UNetMini only")
         x = x_T.to(self.device)
@@ -63,7 +64,12 @@ class _SamplerBase:
             x = self.scheduler.step(eps, t, x, eta=self.eta, noise=nz)
         return x
 
-    def _fused(self, model, x_T, noises, timesteps, cond=None, guidance=1.0):
+    def _fused(self, model, x_T, noises, timesteps, cond=None, guidance=1.0, draw_chunks=False, progress_bar=False):
+        """The whole loop inside libdm_sampler.so (dm_sample_chunked).  ``draw_chunks``: the per-step noise is drawn HERE,
+        from torch's global CPU generator, one graph chunk (<= 50 steps) at a time inside the library's chunk callback -
+        the draw of chunk k+1 overlaps the GPU's work on chunk k, and the values are those of one ``torch.randn((n,) + shape)``
+        (tests/test_sample_driver_cpu.py pins that).  ``progress_bar``: a tqdm bar advanced by the chunk length as chunks
+        COMPLETE on the GPU (the reference ticks per step, sampler.py:65-66; a captured graph cannot)."""
         dev = model.packed_weights().device
         B, Cin, H, W = x_T.shape
         n = timesteps.numel()
@@ -92,32 +98,92 @@ class _SamplerBase:
             cond = cond.to(dev, torch.float32).contiguous()
             if cond.shape != (2 * B, model.time_emb_dim):
                 raise RuntimeError(f"cond must be [{2 * B},{model.time_emb_dim}]")
+        with_noise = nz is not None or draw_chunks
         L = _lib.lib()
-        need = L.dm_sample_workspace_bytes(model._native(), B, H, W, n, 0 if cond is None else 1, 0 if nz is None else 1)
+        need = L.dm_sample_workspace_bytes(model._native(), B, H, W, n, 0 if cond is None else 1, 1 if with_noise else 0)
         ws = model.workspace_bytes(need)
         packed = model.packed_weights()
         cur = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
         side.wait_stream(cur)
+
+        # ---- chunk callback: progress ticks and (draw_chunks) the noise of one chunk, drawn into a ring of pinned buffers
+        S0 = min(n, CHUNK_STEPS)
+        ring = self._noise_ring(S0, x.shape) if draw_chunks and nz is None else None
+        bar = tqdm.tqdm(total=n, desc=self._desc) if progress_bar else None
+        st = {"k": 0, "done": 0, "err": None, "ev": {}}
+
+        def on_chunk(_user, first, count):
+            try:
+                k = st["k"]
+                st["k"] = k + 1
+                if ring is not None or bar is not None:
+                    # everything before this chunk is enqueued: E_k completes when chunk k-1 has.  Buffer k % 3 was last
+                    # read by the copy of chunk k-3, which E_(k-2) covers; two chunks stay queued behind the wait.
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    st["ev"][k] = ev
+                    old = st["ev"].pop(k - 2, None)
+                    if old is not None:
+                        old.synchronize()
+                        if bar is not None:
+                            bar.update((k - 2) * S0 - st["done"])
+                            st["done"] = (k - 2) * S0
+                if ring is None:
+                    return None
+                buf = ring[k % len(ring)][:count]
+                torch.randn(buf.shape, out=buf)  # global CPU generator, loop order (schedulers.py:125-126)
+                return buf.data_ptr()
+            except BaseException as e:  # never unwind through the C frames
+                st["err"] = e
+                return None
+
+        cb = _lib.CHUNK_FN(on_chunk) if (ring is not None or bar is not None) else None
         with torch.cuda.device(dev), torch.cuda.stream(side):
-            _lib.check(L.dm_sample(
+            rc = L.dm_sample_chunked(
                 model._native(), _lib.ptr(packed), _lib.ptr(x), B, H, W, _lib.ptr(ts_dev), _lib.ptr(coefs), n,
-                _lib.ptr(nz), _lib.ptr(cond), float(guidance), _lib.ptr(ws), ws.numel(), 1 if self.use_graph else 0, side.cuda_stream))
-            if nz is not None and nz.device.type != "cuda":
-                side.synchronize()  # the library reads the host noise chunk by chunk on this stream
+                _lib.ptr(nz), 1 if with_noise else 0, cb, None, _lib.ptr(cond), float(guidance), _lib.ptr(ws), ws.numel(),
+                1 if self.use_graph else 0, side.cuda_stream)
+            if st["err"] is not None:
+                side.synchronize()
+                raise st["err"]
+            _lib.check(rc)
+            if (nz is not None and nz.device.type != "cuda") or ring is not None or bar is not None:
+                side.synchronize()  # the library reads host noise chunk by chunk on this stream; the bar ends at n
+        if bar is not None:
+            bar.update(n - st["done"])
+            bar.close()
         cur.wait_stream(side)
         for t_ in (x, ts_dev, coefs, nz, ws, packed, cond):
             if t_ is not None and t_.device.type == "cuda":
                 t_.record_stream(side)
         return x
 
+    def _noise_ring(self, S0, shape):
+        """Three pinned [S0, *shape] staging buffers for the chunk-wise noise draw, kept across calls."""
+        key = (S0, tuple(shape))
+        if getattr(self, "_ring_key", None) != key:
+            self._ring = [torch.empty((S0,) + tuple(shape), dtype=torch.float32).pin_memory() for _ in range(3)]
+            self._ring_key = key
+        return self._ring
+
     def __call__(self, model, shape: Tuple[int, ...], progress_bar: bool = True):
-        """diffusion/sampler.py:45-76 / 136-172.  ``progress_bar`` is accepted; the fused loop
-        is one graph launch per <= 50 steps, so no per-step bar is shown for UNetMini."""
-        x_T, noises = self._draw(shape, self.scheduler.timesteps.numel())
+        """diffusion/sampler.py:45-76 / 136-172.  With this package's UNetMini the loop runs inside the library, one
+        graph launch per <= 50 steps: the bar advances per chunk and the eta > 0 noise is drawn chunk by chunk while
+        the GPU works on the previous chunk (same values, same generator order as the reference's per-step draws)."""
+        n = self.scheduler.timesteps.numel()
+        numel = 1
+        for v in shape[1:]:
+            numel *= int(v)
+        if isinstance(model, UNetMini) and len(shape) == 4 and (int(shape[0]) * numel) % 16 == 0 and shape[0] > 0:
+            # (torch's CPU normal_ fills in blocks of 16 values: draws of a multiple of 16 values concatenate exactly)
+            x_T = torch.randn(shape)
+            return self._fused(model, x_T, None, self.scheduler.timesteps, draw_chunks=self.eta > 0, progress_bar=progress_bar)
+        x_T, noises = self._draw(shape, n)
         return self.sample_from(model, x_T, noises, progress_bar)
 
 
+CHUNK_STEPS = 50  # steps per captured graph / noise staging chunk (dm_api.hip: S0)
 _SIDE = {}
 
 

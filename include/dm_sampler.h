@@ -36,7 +36,15 @@ typedef struct dm_unet dm_unet; /* opaque: geometry + packed-weight offsets + gr
 #define DM_UNET_NUM_PARAMS 88
 
 const char* dm_last_error(void);
+/* ABI version of this header; dm_version() returns the value the library was built with.  A binding checks
+ * them for equality before it calls anything else (2: dm_unet_profile takes the length of its result arrays,
+ * DM_K_COUNT grew, dm_sample accepts host pointers and sizes its workspace with dm_sample_workspace_bytes;
+ * 3: dm_sample_chunked, the fused low-resolution kernel class, the any-geometry kernel classes). */
+#define DM_ABI_VERSION 3
 int dm_version(void);
+/* sha256 over the compiler flags and sources this library was built from (__graft_entry__.build_key); "unkeyed" for a
+ * hand build.  build() compares it with the tree it runs in, so a library built with other flags is not reused. */
+const char* dm_build_key(void);
 
 /* ---- model container: replaces UNetMini.__init__ (diffusion/model.py:72-118) ---------- */
 int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_channels,
@@ -138,6 +146,23 @@ int dm_sample(dm_unet* m, const float* packed_dev, float* x_dev, int B, int H, i
               const float* noise, const float* cond, float guidance,
               void* workspace_dev, size_t workspace_bytes, int use_graph, void* stream);
 
+/* dm_sample with a per-chunk callback (sampler.py:65-66,156-157: the reference ticks a tqdm bar per step and
+ * draws `randn_like` per step INSIDE the loop, schedulers.py:125-129).  The loop is enqueued in chunks of <= 50
+ * steps (one graph launch each); `chunk_fn(user, first, count)` is called on the calling thread before steps
+ * [first, first + count) are enqueued - everything before `first` already is - so a binding can (a) advance its
+ * progress bar by the chunk length and (b) hand over the noise of that chunk only: with_noise != 0 and
+ * noise_all == NULL takes the pointer the callback returns ([count][B,Cin,H,W], host or device; it must stay
+ * valid until the copy enqueued right after the callback has completed - a binding that reuses a ring of k
+ * staging buffers waits, inside the callback, for an event it recorded k - 1 callbacks earlier).  The draw of
+ * chunk k+1 then overlaps the GPU's work on chunk k.  noise_all != NULL: the whole [n,...] tensor as in
+ * dm_sample (the callback's return value is ignored).  chunk_fn may be NULL. */
+typedef const float* (*dm_chunk_fn)(void* user, int first_step, int step_count);
+int dm_sample_chunked(dm_unet* m, const float* packed_dev, float* x_dev, int B, int H, int W,
+                      const int64_t* timesteps, const float* coefs, int n,
+                      const float* noise_all, int with_noise, dm_chunk_fn chunk_fn, void* chunk_user,
+                      const float* cond, float guidance,
+                      void* workspace_dev, size_t workspace_bytes, int use_graph, void* stream);
+
 /* Workspace bytes dm_sample needs: dm_unet_workspace_bytes for the (doubled when `guided`) batch
  * and an n-step table, plus the staging area for one graph chunk of noise when `with_noise`. */
 size_t dm_sample_workspace_bytes(const dm_unet* m, int B, int H, int W, int n, int guided,
@@ -187,8 +212,8 @@ enum {
 };
 int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int64_t* t_dev,
                     const float* coef_host, int B, int H, int W, void* workspace_dev,
-                    size_t workspace_bytes, int reps, void* stream, int* counts, float* ms,
-                    double* flops, double* bytes);
+                    size_t workspace_bytes, int reps, void* stream, int nk, int* counts, float* ms,
+                    double* flops, double* bytes);  /* nk = length of the four result arrays, must equal DM_K_COUNT */
 
 /* ---- single operators (NHWC), exported for the per-kernel parity tests ------------------
  * kind: 0 = Conv2d 3x3 pad 1 (model.py:42,45,47,99,102), 1 = Conv2d 4x4 stride 2 pad 1

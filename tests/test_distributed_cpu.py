@@ -78,3 +78,37 @@ def test_world2_gloo_sharded_equals_single():
     # torch-CPU conv picks batch-size dependent blockings: sharded vs single differ by rounding only
     assert (out - single).abs().max().item() <= 1e-5
     assert torch.equal(out[:2], local)
+
+
+def _run_bench_rehearsal(extra):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, DM_BENCH_REHEARSE_CPU="1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line, nothing else on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_launch_contract_cpu_rehearsal():
+    """The driver's N > 1 launch of bench.py (torch.distributed.run, one rank per GPU), rehearsed on CPU with gloo and a
+    stand-in sampler (DM_BENCH_REHEARSE_CPU): host-side shard slicing, the gather (asserted inside bench.py against the
+    unsharded job), max-over-ranks timing and the JSON line - strong scaling (BASELINE configs[2] form) and weak."""
+    j = _run_bench_rehearsal(["--total-images", "64"])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 2 and j["warmup"] == 1
+    assert j["config"]["images_per_gpu"] == 32 and "64 images sharded over 2 GPUs" in j["config"]["workload"]
+    assert j["config"]["parallelism"].startswith("dp2") and j["unit"] == "images/s" and j["higher_is_better"] is True
+    assert "rehearsal" in j and j["vs_baseline"] is None and j["value"] > 0
+    j = _run_bench_rehearsal(["--batch", "16"])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["images_per_gpu"] == 16
+
+
+def test_gather_buffer_is_reused_and_checked():
+    from diffusion_model_amd.distributed import gather_shards, shard_rows
+    x = torch.arange(24.0).reshape(6, 4)
+    assert torch.equal(shard_rows(x), x) and gather_shards(x) is not None  # world 1: identity
+    assert torch.equal(shard_rows(x.reshape(2, 3, 4), 1), x.reshape(2, 3, 4))

@@ -284,7 +284,7 @@ def test_attention_fused_kernel(B, T, C):
 
 
 def test_steps_not_dividing_T_and_too_many_steps(golden, model, sd):
-    """schedulers.py:146: stride T//n.  n=30 gives 34 ascending steps (golden timesteps_30 holds the reference's list);
+    """schedulers.py:146: stride T//n.  n=30 gives stride 33, i.e. 31 ascending steps 0, 33, ..., 990 (golden timesteps_30 holds the reference's list);
     n > T gives stride 0, which torch.arange rejects in the reference and here alike."""
     sched = d.DDPMScheduler()
     smp = d.DDIMSampler(sched, num_inference_steps=30, eta=0.0)

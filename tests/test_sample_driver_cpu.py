@@ -37,3 +37,29 @@ def test_text_config_parser(tmp_path):
     c = S.load_config(p)
     assert c["image_size"] == 64 and c["beta_end"] == 0.03 and c["beta_schedule"] == "cosine"
     assert c["checkpoint_path"] is None and "unknown" not in c and c["seed"] == 42
+
+
+def test_chunked_noise_draws_equal_one_draw():
+    """AncestralSampler.__call__ draws the eta > 0 noise one 50-step chunk at a time (into pinned staging buffers, while
+    the GPU works on the previous chunk).  torch's CPU normal_ fills contiguous tensors in blocks of 16 values, so draws
+    whose sizes are multiples of 16 concatenate to exactly the one big draw - and to the reference's per-step
+    `randn_like` draws (schedulers.py:125-126).  Pinned here, because parity of __call__ rests on it."""
+    shape = (3, 1, 8, 8)   # 192 values per step
+    n, S0 = 130, 50
+    torch.manual_seed(9)
+    x_a = torch.randn(shape)
+    one = torch.randn((n,) + shape)
+    torch.manual_seed(9)
+    x_b = torch.randn(shape)
+    ring = [torch.empty((S0,) + shape) for _ in range(3)]
+    parts = []
+    for k, first in enumerate(range(0, n, S0)):
+        cnt = min(S0, n - first)
+        buf = ring[k % 3][:cnt]
+        torch.randn(buf.shape, out=buf)
+        parts.append(buf.clone())
+    torch.manual_seed(9)
+    x_c = torch.randn(shape)
+    per_step = torch.stack([torch.randn(shape) for _ in range(n)])
+    assert torch.equal(x_a, x_b) and torch.equal(x_a, x_c)
+    assert torch.equal(one, torch.cat(parts)) and torch.equal(one, per_step)

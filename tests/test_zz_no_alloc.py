@@ -56,3 +56,55 @@ def test_noalloc_forward_matches_workspace_forward(sd):
     rc = L.dm_unet_forward_noalloc(m._native(), _lib.ptr(m.packed_weights()), _lib.ptr(big), _lib.ptr(t1), 1, None,
                                    _lib.ptr(eps), 128, 32, 32, torch.cuda.current_stream().cuda_stream)
     assert rc != 0 and b"static buffer" in L.dm_last_error()
+
+
+@pytest.mark.parametrize("kind", ["bf16", "attention"])
+def test_noalloc_forward_other_workspace_layouts(sd, kind):
+    """the bf16 carve (16-bit activations in the same regions) and the attention carve (T1/T2 reused as
+    QKV / scores) on the static array: every region is written before it is read there too - two calls in a row,
+    the second smaller, against dm_unet_forward on a caller-owned workspace, bit for bit."""
+    L = _lib.lib()
+    if kind == "bf16":
+        m = d.UNetMini(image_size=32, precision="bf16").eval()
+        m.load_state_dict(sd)
+    else:
+        d.set_seed(5)
+        m = d.UNetMini(image_size=32, attention=True).eval()
+    _lib.check(L.dm_init())
+    g = torch.Generator().manual_seed(321)
+    x1 = torch.randn((20, 1, 32, 32), generator=g).to(DEV)
+    x2 = torch.randn((3, 1, 32, 32), generator=g).to(DEV)
+    t1 = torch.tensor([250], device=DEV)
+    ref1, ref2 = m(x1, t1), m(x2, t1)
+    # poison the static array through a large fp32 call of another model first: stale contents must not matter
+    big = d.UNetMini(image_size=32).eval()
+    _fwd_noalloc(big, torch.randn((40, 1, 32, 32), generator=g).to(DEV) * 50.0, t1, torch.empty((40, 1, 32, 32), device=DEV))
+    a1 = _fwd_noalloc(m, x1, t1, torch.empty_like(ref1))
+    a2 = _fwd_noalloc(m, x2, t1, torch.empty_like(ref2))
+    assert torch.equal(a1, ref1) and torch.equal(a2, ref2)
+
+
+def test_noalloc_forward_under_graph_capture(sd):
+    """The header names hipGraph capture as a use: capture one call (after dm_init and a warm-up call, which set the
+    kernels' attributes), replay it twice on new inputs, compare with dm_unet_forward bit for bit."""
+    L = _lib.lib()
+    m = d.UNetMini(image_size=32).eval()
+    m.load_state_dict(sd)
+    _lib.check(L.dm_init())
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn((6, 1, 32, 32), generator=g).to(DEV)
+    t = torch.tensor([700], device=DEV)
+    eps = torch.empty_like(x)
+    _fwd_noalloc(m, x, t, eps)  # warm-up outside capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        _lib.check(L.dm_unet_forward_noalloc(m._native(), _lib.ptr(m.packed_weights()), _lib.ptr(x), _lib.ptr(t), 1, None,
+                                             _lib.ptr(eps), 6, 32, 32, torch.cuda.current_stream().cuda_stream))
+    for seed in (1, 2):
+        xn = torch.randn((6, 1, 32, 32), generator=torch.Generator().manual_seed(seed)).to(DEV)
+        x.copy_(xn)
+        eps.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(eps, m(xn, t))
