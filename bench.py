@@ -45,7 +45,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 K_NAMES = ["init_conv", "conv3x3_mfma_t128", "conv3x3_mfma_t64", "conv4x4s2_mfma", "convT4x4s2_mfma_t128",
            "convT4x4s2_mfma_t64", "final_conv", "time_embed", "sampler_step", "attention", "conv3x3_winograd_mfma",
-           "conv3x3_bf16x6_mfma", "conv4x4s2_bf16x6_mfma", "convT4x4s2_bf16x6_mfma"]
+           "conv3x3_bf16x6_mfma", "conv4x4s2_bf16x6_mfma", "convT4x4s2_bf16x6_mfma", "conv_any_geometry_mfma", "groupnorm_silu_any_geometry",
+           "lowres_fused_bf16x6_mfma"]
 NK = len(K_NAMES)  # DM_K_COUNT
 K_WINO = 10
 MFMA_CLASSES = (1, 2, 3, 4, 5, 9, 10, 11, 12, 13)

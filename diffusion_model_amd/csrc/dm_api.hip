@@ -6,6 +6,7 @@
 #include "dm_kernels_bf16.hip"
 #include "dm_kernels_x6.hip"
 #include "dm_kernels_init5.hip"
+#include "dm_kernels_generic.hip"
 #include "../../include/dm_sampler.h"
 
 #include <hip/hip_runtime.h>
@@ -415,12 +416,21 @@ size_t conv_packed_floats(int kind, int cin, int cout) {
     return ((size_t)taps * cin * cout * 3 + 1) / 2;
   }
   if (kind == 6) kind = 1;  // same packed weights
+  if (kind >= 10 && kind <= 12) kind -= 10;  // any-geometry kernels: the direct form, output channels padded to 32
   const int taps = kind == 0 ? 9 : kind == 3 ? 1 : 16;  // KIND 2: 4 parities x 4 taps; KIND 5: 16 transform points
-  return (size_t)taps * cin * cout;
+  return (size_t)taps * cin * ((cout + 31) / 32 * 32);
 }
 
 int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream_t s, int bf16 = 0) {
   if (kind == 6) kind = 1;
+  if (kind >= 10 && kind <= 12) kind -= 10;
+  if (!bf16 && kind <= 2 && (cin % 16 || cout % 32)) {  // any-geometry form (gconv_kernel): cin % 8, any cout (zero-padded to 32)
+    if (cin % 8 || cin <= 0 || cout <= 0) return fail("pack_conv: input channels must be a positive multiple of 8 (got %d -> %d)", cin, cout);
+    const size_t total = conv_packed_floats(kind, cin, cout);
+    hipLaunchKernelGGL(gpack_conv_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind, w, cin, cout, out, total);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (cin % 16 || cout % 32) return fail("pack_conv: cin %% 16 / cout %% 32");
   if (kind >= 7 && kind <= 9) {
     const size_t total = (size_t)(kind == 7 ? 9 : 16) * cin * cout;
@@ -473,6 +483,8 @@ struct dm_unet {
   size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb, o_b0w, o_b3w, o_b0x, o_b3x;
   size_t o_i5w;        // init_conv composed with down1.conv1: nine weight sets (init5_kernel)
   int init5;           // 1: that composition replaces the two layers where the tile geometry allows (env DM_INIT5, default 1)
+  int fast;            // C in {64,128,256,512}, in/out channels <= 4: the tuned kernels apply (to power-of-two image sides);
+                       // otherwise every geometry runs on the any-geometry kernels (dm_kernels_generic.hip)
   size_t total;
   std::vector<GraphEntry> graphs;
 };
@@ -508,6 +520,10 @@ size_t max_stats_partials(int H, int W, int C) {
   return (size_t)pm;
 }
 
+// Do the tuned kernels (power-of-two tiles, Winograd / split-bf16 weight forms) cover HxW images of this model?
+// Everything else the reference accepts (H, W divisible by 8; C divisible by 8) runs on dm_kernels_generic.hip.
+bool tuned_geometry(const dm_unet* m, int H, int W) { return m->fast && is_pow2(H) && is_pow2(W) && H >= 8 && W >= 8; }
+
 // Carve the workspace for a denoiser batch B (all offsets 256-B aligned).  Everything whose
 // address a captured graph bakes in and whose size does not depend on the number of steps
 // comes first, so those addresses are a function of (B, H, W) only; the step-count-dependent
@@ -536,7 +552,7 @@ Workspace carve(const dm_unet* m, void* base, int B, int H, int W, int nsteps, s
   w.BT = take(full / 64);
   w.U1 = take(full / 16);
   w.U2 = take(full / 4);
-  w.stats_floats = (size_t)B * max_stats_partials(H, W, m->C) * DM_GROUPS * 2;
+  w.stats_floats = (size_t)B * (tuned_geometry(m, H, W) ? max_stats_partials(H, W, m->C) : 1) * DM_GROUPS * 2;
   w.SA = take(w.stats_floats);
   w.SB = take(w.stats_floats);
   const size_t nt = (size_t)(nsteps > B ? nsteps : B);
@@ -554,10 +570,14 @@ int launch_final(const float* u, int bf16, const float* stats, int pin, float cn
 
 int check_geometry(const dm_unet* m, int B, int H, int W) {
   if (B <= 0) return fail("batch must be positive (got %d)", B);
-  if (!is_pow2(H) || !is_pow2(W) || H < 8 || W < 8)
-    return fail("image height/width must be powers of two >= 8 (three 2x down-samplings; got %dx%d)", H, W);
-  if (m->bf16 && (H < 16 || W < 16))
-    return fail("the bf16 kernels need image height/width >= 16 (got %dx%d); use fp32 for smaller images", H, W);
+  // model.py:138-148: three 2x down-samplings and the skip concatenations need H, W divisible by 8 (the
+  // reference raises a RuntimeError from torch.cat otherwise)
+  if (H < 8 || W < 8 || H % 8 || W % 8)
+    return fail("image height/width must be multiples of 8 (three 2x down-samplings; got %dx%d)", H, W);
+  if (m->bf16 && (!tuned_geometry(m, H, W) || H < 16 || W < 16))
+    return fail("the bf16 kernels need power-of-two image height/width >= 16 (got %dx%d); use fp32 for other sizes", H, W);
+  if (m->attn && !tuned_geometry(m, H, W))
+    return fail("the (build-defined) attention blocks need power-of-two image height/width (got %dx%d)", H, W);
   return 0;
 }
 
@@ -721,6 +741,129 @@ bool shares_first_layers(const dm_unet* m, int B, int H, int W, int dup_half) {
   return dup_half > 0 && B == 2 * dup_half && !noshare && uses_init5(m, H, W);
 }
 
+// ------------------------------------------------------------------ any-geometry path (dm_kernels_generic.hip)
+int launch_gconv(int kind, const float* x1, int c1, const float* x2, int c2, const float* wp, const float* bias, int cout,
+                 float* y, int B, int H, int W, hipStream_t s) {
+  if (kind < 0 || kind > 2) return fail("conv (any geometry): kind %d is not 3x3 / 4x4 stride 2 / transposed 4x4", kind);
+  if (B <= 0 || H <= 0 || W <= 0) return fail("conv: empty input");
+  if (c1 <= 0 || c1 % 8 || c2 % 8 || cout <= 0) return fail("conv (any geometry): input channel counts must be multiples of 8 (got %d+%d -> %d)", c1, c2, cout);
+  if (kind == 1 && (H % 2 || W % 2)) return fail("conv: the stride-2 conv needs even H, W (got %dx%d)", H, W);
+  GConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.x1 = x1; a.x2 = c2 ? x2 : nullptr; a.wp = wp; a.bias = bias; a.y = y;
+  a.B = B; a.H = H; a.W = W; a.C1 = c1; a.C2 = c2; a.Cout = cout;
+  a.OH = kind == 1 ? H / 2 : kind == 2 ? 2 * H : H;
+  a.OW = kind == 1 ? W / 2 : kind == 2 ? 2 * W : W;
+  a.Hb = kind == 1 ? H / 2 : H; a.Wb = kind == 1 ? W / 2 : W;
+  a.tiles_x = (a.Wb + 7) / 8; a.tiles_y = (a.Hb + 7) / 8;
+  a.nb32 = (cout + 31) / 32;
+  const size_t nblk = (size_t)B * a.tiles_x * a.tiles_y;
+  if (nblk > 0x7fffffffull) return fail("conv (any geometry): %zu tiles exceed the grid limit", nblk);
+  const dim3 grid((unsigned)nblk, (unsigned)((cout + 63) / 64), kind == 2 ? 4u : 1u);
+  const double taps = kind == 0 ? 9 : 16, cin = c1 + c2;
+  ProfScope ps(DM_K_GENERIC_CONV, s, 2.0 * B * a.Hb * a.Wb * cout * taps * cin,
+               4.0 * ((double)B * H * W * cin + (double)B * a.OH * a.OW * cout + taps * cin * cout));
+  if (kind == 0) hipLaunchKernelGGL(gconv_kernel<0>, grid, dim3(256), 0, s, a);
+  else if (kind == 1) hipLaunchKernelGGL(gconv_kernel<1>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gconv_kernel<2>, grid, dim3(256), 0, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// x <- SiLU(GroupNorm8(x)) + temb in place: statistics kernel, then the elementwise kernel (model.py:54-62, 100-101)
+int launch_gnorm(float* x, float* stats, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                 int temb_step_stride, const int* step_ptr, int step_off, int B, int HW, int C, hipStream_t s) {
+  if (C % 8 || C <= 0) return fail("GroupNorm(8): channels must be a multiple of 8 (got %d)", C);
+  if ((size_t)B * DM_GROUPS > 0x7fffffffull) return fail("GroupNorm: batch too large");
+  ProfScope ps(DM_K_GENERIC_NORM, s, 12.0 * B * HW * C, 16.0 * B * HW * C);
+  hipLaunchKernelGGL(gstats_kernel, dim3((unsigned)(B * DM_GROUPS)), dim3(256), 0, s, x, stats, HW, C);
+  HIP_TRY(hipGetLastError());
+  GNormArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.temb = temb; a.step_ptr = step_ptr; a.step_off = step_off;
+  a.temb_stride = temb_stride; a.temb_step_stride = temb_step_stride; a.HW = HW; a.C = C;
+  a.ppb = 16384 / C > 0 ? 16384 / C : 1;
+  a.chunks = (HW + a.ppb - 1) / a.ppb;
+  const size_t lds = (size_t)3 * C * sizeof(float);
+  if (lds > 64 * 1024) return fail("GroupNorm: %d channels exceed the table size", C);
+  hipLaunchKernelGGL(gnorm_kernel, dim3((unsigned)((size_t)B * a.chunks)), dim3(256), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_gfinal(const float* u, float* stats, const float* gamma, const float* beta, const float* wt, const float* bias,
+                  float* out, int B, int HW, int C, int Cout, hipStream_t s) {
+  ProfScope ps(DM_K_FINAL, s, 2.0 * B * HW * C * Cout, 4.0 * B * HW * (2.0 * C + Cout));
+  hipLaunchKernelGGL(gstats_kernel, dim3((unsigned)(B * DM_GROUPS)), dim3(256), 0, s, u, stats, HW, C);
+  HIP_TRY(hipGetLastError());
+  const int ppb = 64;
+  const int chunks = (HW + ppb - 1) / ppb;
+  const size_t lds = (size_t)(2 * C + Cout * C) * sizeof(float);
+  if (lds > 160 * 1024) return fail("final_conv: %d x %d weights exceed the CU's LDS", Cout, C);
+  if (lds > 48 * 1024) {
+    static bool attr_done[DM_MAX_DEVICES] = {false};
+    const int dev = current_device();
+    if (!attr_done[dev]) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gfinal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done[dev] = true;
+    }
+  }
+  hipLaunchKernelGGL(gfinal_kernel, dim3((unsigned)((size_t)B * chunks)), dim3(256), lds, s, u, stats, gamma, beta, wt, bias, out, HW, C,
+                     Cout, ppb, chunks);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_init_conv(const dm_unet* m, const float* P, const float* x, float* y, int B, int H, int W, hipStream_t s) {
+  const int C = m->C;
+  const size_t lds = (size_t)m->Cin * 9 * C * sizeof(float);
+  if (lds > 160 * 1024) return fail("init_conv: %d x %d channels exceed the CU's LDS", m->Cin, C);
+  if (lds > 48 * 1024) {
+    static bool attr_done[DM_MAX_DEVICES] = {false};
+    const int dev = current_device();
+    if (!attr_done[dev]) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&init_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_done[dev] = true;
+    }
+  }
+  const size_t total = (size_t)B * H * W * (C / 4);
+  unsigned blocks = (unsigned)((total + 255) / 256 > 65536u * 4 ? 65536u * 4 : (total + 255) / 256);
+  ProfScope ps(DM_K_INIT, s, 2.0 * B * H * W * C * 9 * m->Cin, 4.0 * B * H * W * (m->Cin + C));
+  hipLaunchKernelGGL(init_conv_kernel, dim3(blocks), dim3(256), lds, s, x, P + m->o_initw, P + m->o_initb, y, B, m->Cin, H, W, C);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// model.py:135-151 for any H, W divisible by 8 and any C divisible by 8: the layer sequence of unet_body, each
+// GroupNorm+SiLU(+temb) as its own pair of kernels, every convolution on gconv_kernel.
+int unet_body_generic(const dm_unet* m, const float* P, const float* x, float* eps, const float* heads,
+                      int heads_img_stride, int heads_step_stride, const int* step_ptr, int step_off,
+                      const Workspace& w, int B, int H, int W, hipStream_t s) {
+  const int C = m->C;
+  if (m->bf16 || m->attn) return fail("internal: the any-geometry path is fp32 without attention");
+  if (launch_init_conv(m, P, x, w.A0, B, H, W, s)) return 1;
+  auto block = [&](int k, const float* in1, const float* in2, int h, int ww, bool up, float* out) -> int {
+    const BlockOff& o = m->blk[k];
+    if (launch_gconv(0, in1, C, in2, in2 ? C : 0, P + o.c1, P + o.c1b, C, w.T1, B, h, ww, s)) return 1;
+    if (launch_gnorm(w.T1, w.SA, P + o.g1, P + o.b1, heads + (size_t)k * C, heads_img_stride, heads_step_stride, step_ptr, step_off,
+                     B, h * ww, C, s)) return 1;
+    if (launch_gconv(0, w.T1, C, nullptr, 0, P + o.c2, P + o.c2b, C, w.T2, B, h, ww, s)) return 1;
+    if (launch_gnorm(w.T2, w.SA, P + o.g2, P + o.b2, nullptr, 0, 0, nullptr, 0, B, h * ww, C, s)) return 1;
+    return launch_gconv(up ? 2 : 1, w.T2, C, nullptr, 0, P + o.tr, P + o.trb, C, out, B, h, ww, s);
+  };
+  if (block(0, w.A0, nullptr, H, W, false, w.D1)) return 1;
+  if (block(1, w.D1, nullptr, H / 2, W / 2, false, w.D2)) return 1;
+  if (block(2, w.D2, nullptr, H / 4, W / 4, false, w.D3)) return 1;
+  const int hb = H / 8, wb = W / 8;
+  if (launch_gconv(0, w.D3, C, nullptr, 0, P + m->o_b0, P + m->o_b0b, C, w.BT0, B, hb, wb, s)) return 1;
+  if (launch_gnorm(w.BT0, w.SA, P + m->o_bg, P + m->o_bb, nullptr, 0, 0, nullptr, 0, B, hb * wb, C, s)) return 1;
+  if (launch_gconv(0, w.BT0, C, nullptr, 0, P + m->o_b3, P + m->o_b3b, C, w.BT, B, hb, wb, s)) return 1;
+  if (block(3, w.BT, w.D3, hb, wb, true, w.U1)) return 1;
+  if (block(4, w.U1, w.D2, H / 4, W / 4, true, w.U2)) return 1;
+  if (block(5, w.U2, w.D1, H / 2, W / 2, true, w.A0)) return 1;
+  return launch_gfinal(w.A0, w.SA, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H * W, C, m->Cout, s);
+}
+
 // One denoiser evaluation (everything after the time embedding): model.py:135-151.
 // heads: [.., 6, C] table; heads_img_stride = 6*C when every image has its own timestep
 // (training-style [B] t) else 0; in the sampling loop the table is indexed by the step
@@ -731,6 +874,8 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
               int heads_img_stride, int heads_step_stride, const int* step_ptr, int step_off,
               const Workspace& w, int B, int H, int W, hipStream_t s, int dup_half = 0) {
   const int C = m->C;
+  if (!tuned_geometry(m, H, W))
+    return unet_body_generic(m, P, x, eps, heads, heads_img_stride, heads_step_stride, step_ptr, step_off, w, B, H, W, s);
   // init_conv (model.py:135) is folded into down1.conv1's staging (no kernel, no HBM round trip)
   // (also in bf16: the stand-alone init kernel + a plain first layer take 343 + 163 us at B = 2048, the folded layer 420)
   const int x6 = m->bf16 ? 0 : m->x6;
@@ -935,6 +1080,7 @@ int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_c
 int dm_unet_set_precision(dm_unet* m, int bf16) {
   if (!m) return fail("dm_unet_set_precision: null handle");
   if (bf16 && m->attn) return fail("the bf16 path does not cover the attention blocks");
+  if (bf16 && !m->fast) return fail("the bf16 kernels need model_channels in {64,128,256,512} and in/out channels <= 4");
   m->bf16 = bf16 ? 1 : 0;
   for (auto& g : m->graphs) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
   m->graphs.clear();
@@ -946,16 +1092,21 @@ int dm_unet_num_params(const dm_unet* m) { return m ? DM_UNET_NUM_PARAMS + (m->a
 int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int model_channels, int time_emb_dim,
                       int attention) {
   if (!out) return fail("dm_unet_create: null out");
-  if (in_channels < 1 || in_channels > 4 || out_channels < 1 || out_channels > 4)
-    return fail("in/out channels must be in 1..4 (got %d, %d)", in_channels, out_channels);
-  if (model_channels != 64 && model_channels != 128 && model_channels != 256 && model_channels != 512)
-    return fail("model_channels must be one of 64, 128, 256, 512 (got %d)", model_channels);
+  if (in_channels < 1 || in_channels > 64 || out_channels < 1 || out_channels > 64)
+    return fail("in/out channels must be in 1..64 (got %d, %d)", in_channels, out_channels);
+  // model.py:48-49,100,112: nn.GroupNorm(8, C) needs C divisible by 8 (torch raises a ValueError otherwise)
+  if (model_channels < 8 || model_channels % 8 || model_channels > 2048)
+    return fail("model_channels must be a multiple of 8 in 8..2048 (GroupNorm(8, C); got %d)", model_channels);
+  const bool fast = (model_channels == 64 || model_channels == 128 || model_channels == 256 || model_channels == 512) &&
+                    in_channels <= 4 && out_channels <= 4;
+  if (attention && !fast) return fail("the (build-defined) attention blocks need model_channels in {64,128,256,512} and in/out channels <= 4");
   if (time_emb_dim < 4 || time_emb_dim % 2 || time_emb_dim > 1024)
     return fail("time_emb_dim must be even, in 4..1024 (got %d)", time_emb_dim);
   dm_unet* m = new dm_unet();
   m->Cin = in_channels; m->Cout = out_channels; m->C = model_channels; m->E = time_emb_dim;
   m->attn = attention ? 1 : 0;
   m->bf16 = 0;
+  m->fast = fast ? 1 : 0;
   m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 31 : DM_X6_DEFAULT;
   m->init5 = getenv("DM_INIT5") ? (atoi(getenv("DM_INIT5")) != 0) : 1;
   const int C = m->C, E = m->E;
@@ -972,13 +1123,18 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
     b.tr = take(conv_packed_floats(up ? 2 : 1, C, C)); b.trb = take(C);
     b.c2 = take(conv_packed_floats(0, C, C)); b.c2b = take(C);
     b.g1 = take(C); b.b1 = take(C); b.g2 = take(C); b.b2 = take(C);
+    if (!fast) { b.c1w = b.c2w = b.c1x = b.c2x = b.trx = 0; continue; }  // (Winograd / split-bf16 forms: tuned kernels only)
     b.c1w = take(conv_packed_floats(5, up ? 2 * C : C, C)); b.c2w = take(conv_packed_floats(5, C, C));
     b.c1x = take(conv_packed_floats(7, up ? 2 * C : C, C)); b.c2x = take(conv_packed_floats(7, C, C));
     b.trx = take(conv_packed_floats(up ? 9 : 8, C, C));
   }
-  m->o_b0w = take(conv_packed_floats(5, C, C)); m->o_b3w = take(conv_packed_floats(5, C, C));
-  m->o_b0x = take(conv_packed_floats(7, C, C)); m->o_b3x = take(conv_packed_floats(7, C, C));
-  m->o_i5w = take((size_t)9 * (25 * m->Cin + 1) * C);
+  if (fast) {
+    m->o_b0w = take(conv_packed_floats(5, C, C)); m->o_b3w = take(conv_packed_floats(5, C, C));
+    m->o_b0x = take(conv_packed_floats(7, C, C)); m->o_b3x = take(conv_packed_floats(7, C, C));
+    m->o_i5w = take((size_t)9 * (25 * m->Cin + 1) * C);
+  } else {
+    m->o_b0w = m->o_b3w = m->o_b0x = m->o_b3x = m->o_i5w = 0;
+  }
   m->o_b0 = take(conv_packed_floats(0, C, C)); m->o_b0b = take(C);
   m->o_bg = take(C); m->o_bb = take(C);
   m->o_b3 = take(conv_packed_floats(0, C, C)); m->o_b3b = take(C);
@@ -1030,7 +1186,8 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
   if (copy(m->o_tm1w, p[i++], (size_t)E * E) || copy(m->o_tm1b, p[i++], E) ||
       copy(m->o_tm2w, p[i++], (size_t)E * E) || copy(m->o_tm2b, p[i++], E) ||
       copy(m->o_initw, p[i++], (size_t)C * m->Cin * 9) || copy(m->o_initb, p[i++], C)) return 1;
-  {  // init_conv o down1.conv1 as one 5x5 convolution (dm_kernels_init5.hip): p[4], p[5] = init_conv, p[8], p[9] = down1.conv1
+  const bool xf = m->fast && !m->bf16;  // Winograd / split-bf16 weight forms (fp32 tuned kernels)
+  if (m->fast) {  // init_conv o down1.conv1 as one 5x5 convolution (dm_kernels_init5.hip): p[4], p[5] = init_conv, p[8], p[9] = down1.conv1
     const size_t n1 = (size_t)9 * (25 * m->Cin + 1) * C;
     hipLaunchKernelGGL(pack_init5_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, p[4], p[5], p[8], p[9], m->Cin, C,
                        packed + m->o_i5w);
@@ -1040,17 +1197,17 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
     const bool up = k >= 3;
     const BlockOff& b = m->blk[k];
     if (copy(b.tmw, p[i++], (size_t)C * E) || copy(b.tmb, p[i++], C)) return 1;
-    if (!m->bf16 && (pack_conv(5, p[i], up ? 2 * C : C, C, packed + b.c1w, s) || pack_conv(7, p[i], up ? 2 * C : C, C, packed + b.c1x, s))) return 1;
+    if (xf && (pack_conv(5, p[i], up ? 2 * C : C, C, packed + b.c1w, s) || pack_conv(7, p[i], up ? 2 * C : C, C, packed + b.c1x, s))) return 1;
     if (pack_conv(0, p[i++], up ? 2 * C : C, C, packed + b.c1, s, m->bf16) || copy(b.c1b, p[i++], C)) return 1;
-    if (!m->bf16 && pack_conv(up ? 9 : 8, p[i], C, C, packed + b.trx, s)) return 1;
+    if (xf && pack_conv(up ? 9 : 8, p[i], C, C, packed + b.trx, s)) return 1;
     if (pack_conv(up ? 2 : 1, p[i++], C, C, packed + b.tr, s, m->bf16) || copy(b.trb, p[i++], C)) return 1;
-    if (!m->bf16 && (pack_conv(5, p[i], C, C, packed + b.c2w, s) || pack_conv(7, p[i], C, C, packed + b.c2x, s))) return 1;
+    if (xf && (pack_conv(5, p[i], C, C, packed + b.c2w, s) || pack_conv(7, p[i], C, C, packed + b.c2x, s))) return 1;
     if (pack_conv(0, p[i++], C, C, packed + b.c2, s, m->bf16) || copy(b.c2b, p[i++], C)) return 1;
     if (copy(b.g1, p[i++], C) || copy(b.b1, p[i++], C) || copy(b.g2, p[i++], C) || copy(b.b2, p[i++], C)) return 1;
     return 0;
   };
   for (int k = 0; k < 3; ++k) if (do_block(k)) return 1;
-  if (!m->bf16 && (pack_conv(5, p[i], C, C, packed + m->o_b0w, s) || pack_conv(5, p[i + 4], C, C, packed + m->o_b3w, s) ||
+  if (xf && (pack_conv(5, p[i], C, C, packed + m->o_b0w, s) || pack_conv(5, p[i + 4], C, C, packed + m->o_b3w, s) ||
                    pack_conv(7, p[i], C, C, packed + m->o_b0x, s) || pack_conv(7, p[i + 4], C, C, packed + m->o_b3x, s))) return 1;
   if (pack_conv(0, p[i++], C, C, packed + m->o_b0, s, m->bf16) || copy(m->o_b0b, p[i++], C) ||
       copy(m->o_bg, p[i++], C) || copy(m->o_bb, p[i++], C) ||
@@ -1353,7 +1510,7 @@ size_t dm_conv_packed_floats(int kind, int cin, int cout) { return conv_packed_f
 
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev, void* stream) {
   if (!w_dev || !packed_dev) return fail("dm_pack_conv_weight: null argument");
-  if (kind < 0 || kind == 4 || kind > 9) return fail("unknown conv kind %d", kind);
+  if (kind < 0 || kind == 4 || kind > 12) return fail("unknown conv kind %d", kind);
   return pack_conv(kind, w_dev, cin, cout, packed_dev, (hipStream_t)stream);
 }
 
@@ -1364,6 +1521,13 @@ int dm_conv_stats_partials(int kind, int H, int W) {
   if (kind < 0 || kind == 4 || kind > 9 || !is_pow2(H) || !is_pow2(W)) return 0;
   if (kind >= 7) kind = x6_base_kind(kind, H, W);
   return conv_geo(kind, H, W, 64).pout;
+}
+
+int dm_groupnorm_silu(float* x_dev, const float* gamma, const float* beta, const float* temb, int temb_stride,
+                      float* stats_dev, int B, int H, int W, int C, void* stream) {
+  if (!x_dev || !gamma || !beta || !stats_dev) return fail("dm_groupnorm_silu: null argument");
+  if (B <= 0 || H <= 0 || W <= 0) return fail("dm_groupnorm_silu: empty input");
+  return launch_gnorm(x_dev, stats_dev, gamma, beta, temb, temb_stride, 0, nullptr, 0, B, H * W, C, (hipStream_t)stream);
 }
 
 int dm_conv2d(int kind, const float* x1, int c1, const float* x2, int c2, const float* wp, const float* bias,
@@ -1377,6 +1541,10 @@ int dm_conv2d(int kind, const float* x1, int c1, const float* x2, int c2, const 
   c.kind = kind; c.x1 = x1; c.c1 = c1; c.x2 = c2 ? x2 : nullptr; c.c2 = c2; c.wp = wp; c.bias = bias; c.cout = cout;
   c.stats_in = stats_in; c.pin = pin; c.cnt_in = cnt_in; c.gamma = gamma; c.beta = beta;
   c.temb = temb; c.temb_stride = temb_stride; c.y = y; c.stats_out = stats_out; c.B = B; c.H = H; c.W = W;
+  if (kind >= 10 && kind <= 12) {  // any-geometry kernels: plain convolution (the GroupNorm transform is dm_groupnorm_silu)
+    if (stats_in || stats_out || temb) return fail("dm_conv2d: kinds 10-12 take no fused GroupNorm transform / statistics");
+    return launch_gconv(kind - 10, x1, c1, c2 ? x2 : nullptr, c2, wp, bias, cout, y, B, H, W, (hipStream_t)stream);
+  }
   if (kind >= 7 && kind <= 9) { c.x6 = 1; c.kind = x6_base_kind(kind, H, W); }
   return launch_conv(c, (hipStream_t)stream);
 }

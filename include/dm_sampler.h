@@ -208,7 +208,10 @@ enum {
   DM_K_X6_CONV3 = 11, /* conv_x6_kernel<.,0>: 3x3 convs on the bf16 pipe, 3-way split operands (6 MFMAs per fp32 product) */
   DM_K_X6_DOWN = 12,  /* conv_x6_kernel<.,1>: 4x4 stride-2 convs, same arithmetic                   */
   DM_K_X6_UP = 13,    /* conv_x6_kernel<.,4>: transposed 4x4 s2 convs, same arithmetic              */
-  DM_K_COUNT = 14
+  DM_K_GENERIC_CONV = 14, /* gconv_kernel<.>: every convolution of geometries outside the tuned set (any H, W % 8, any C % 8), fp32 MFMA */
+  DM_K_GENERIC_NORM = 15, /* gstats_kernel + gnorm_kernel: GroupNorm + SiLU + temb as stand-alone passes, same geometries (HBM-bound) */
+  DM_K_LOWRES = 16,       /* lowres_fused_kernel: the levels at and below 8x8 pixels of the 32x32 model in ONE launch, activations in LDS */
+  DM_K_COUNT = 17
 };
 int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int64_t* t_dev,
                     const float* coef_host, int B, int H, int W, void* workspace_dev,
@@ -224,7 +227,11 @@ int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int
  * weights as kind 1), 7 / 8 / 9 = kinds 0 / 1 / 2 computed on the bf16 matrix pipe with fp32-equivalent accuracy:
  * every fp32 operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation
  * (conv_x6_kernel; own packed-weight format, 1.5 floats per weight; what dm_unet_forward uses for its
- * stride-2 and transposed convolutions and for the 3x3 convolutions at 4x4 pixels: DM_X6). */
+ * stride-2 and transposed convolutions and for the 3x3 convolutions at 4x4 pixels: DM_X6),
+ * 10 / 11 / 12 = kinds 0 / 1 / 2 on the any-geometry kernel (gconv_kernel: any H, W; cin % 8 == 0; any cout; no fused
+ * GroupNorm transform or statistics - see dm_groupnorm_silu): what dm_unet_forward uses whenever the image sides are
+ * not powers of two or model_channels is outside {64,128,256,512} (model.py:72-73,120-151 accept any H, W % 8 == 0 and
+ * any C % 8 == 0). */
 size_t dm_conv_packed_floats(int kind, int cin, int cout);
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev,
                         void* stream);
@@ -236,6 +243,11 @@ int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* 
  * [B][pout][8][2] partial statistics of y (pout as dm_conv_stats_partials reports).
  * H, W are the INPUT spatial dims. */
 int dm_conv_stats_partials(int kind, int H, int W);
+/* x <- SiLU(GroupNorm8(x; gamma, beta)) + temb in place (Block.forward model.py:54-62; bottleneck model.py:100-101), NHWC
+ * [B,H,W,C], any C % 8 == 0: the stand-alone form the any-geometry path uses (statistics kernel + elementwise kernel).
+ * temb_dev: NULL or [*,C] with per-image stride temb_stride (0 = shared).  stats_dev: scratch, B*16 floats. */
+int dm_groupnorm_silu(float* x_dev, const float* gamma_dev, const float* beta_dev, const float* temb_dev,
+                      int temb_stride, float* stats_dev, int B, int H, int W, int C, void* stream);
 /* Build-defined attention core (no reference counterpart: model.py:70 "No attention layers"; BASELINE configs[4]):
  * o[b,t,:] = softmax_s(q[b,t,:] . k[b,s,:] / sqrt(C)) v[b,s,:], single head, qkv_dev [B][T][3C] (q | k | v per token),
  * o_dev [B][T][C].  One fused kernel per (image, 64-query tile): QK^T on fp32 MFMA into a 64 x T score tile in LDS,

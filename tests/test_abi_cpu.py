@@ -78,7 +78,11 @@ def test_scheduler_surface_and_tables(golden):
 def test_geometry_queries_and_argument_errors():
     L = _lib.lib()
     h = C.c_void_p()
-    assert L.dm_unet_create(C.byref(h), 1, 1, 48, 128) != 0 and b"model_channels" in L.dm_last_error()
+    assert L.dm_unet_create(C.byref(h), 1, 1, 36, 128) != 0 and b"model_channels" in L.dm_last_error()  # GroupNorm(8, C)
+    _lib.check(L.dm_unet_create(C.byref(h), 3, 5, 48, 128))  # any C % 8 == 0, any channel counts (model.py:72-73)
+    assert L.dm_unet_packed_floats(h) > 0 and L.dm_unet_workspace_bytes(h, 2, 24, 40, 1) > 0
+    assert L.dm_conv_packed_floats(10, 24, 40) == 9 * 24 * 64  # output channels padded to a multiple of 32
+    L.dm_unet_destroy(h)
     _lib.check(L.dm_unet_create(C.byref(h), 1, 1, 64, 128))
     assert L.dm_unet_packed_floats(h) > 1_106_241  # packed blob holds every parameter (+ padding)
     w1, w2 = L.dm_unet_workspace_bytes(h, 8, 32, 32, 1), L.dm_unet_workspace_bytes(h, 16, 32, 32, 1)

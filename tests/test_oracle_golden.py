@@ -93,3 +93,22 @@ def test_strict_numpy_step_matches_torch_step():
             a = O.sampler_step_np(sched, e, t, x, eta, nz)
             b = O.sampler_step(sched, e, torch.tensor(t), x, eta, nz)
             assert mad(a, b) <= 1e-6 * max(1.0, b.abs().max().item())
+
+
+def test_oracle_matches_reference_on_other_geometries():
+    """The restatement against the real reference's outputs for image sides that are not powers of two and channel
+    counts outside the tuned set (oracle/gen_golden_geometries.py): the oracle is what the GPU tests of those
+    geometries lean on beyond the stored vectors."""
+    import os
+    import diffusion_model_amd as d
+    G = torch.load(os.path.join(os.path.dirname(__file__), "golden", "golden_geometries.pt"), weights_only=True)
+    for size, cin, cout, C, (H, W) in [(24, 1, 1, 32, (24, 24)), (40, 3, 3, 96, (40, 40)), (56, 2, 5, 72, (56, 24))]:
+        key = f"s{size}_i{cin}_o{cout}_c{C}_{H}x{W}"
+        d.set_seed(100 + size + C)
+        m = d.UNetMini(image_size=size, in_channels=cin, out_channels=cout, model_channels=C)
+        sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        with torch.no_grad():
+            e = O.unet_forward(sd, G[key + "/x"], torch.tensor(321))
+            eb = O.unet_forward(sd, G[key + "/x"], G[key + "/tb"])
+        assert (e - G[key + "/eps_t321"]).abs().max().item() <= 1e-6
+        assert (eb - G[key + "/eps_tb"]).abs().max().item() <= 1e-6
