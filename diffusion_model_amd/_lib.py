@@ -46,6 +46,7 @@ _SIGS = {
     "dm_conv_packed_floats": (_sz, [_i, _i, _i]),
     "dm_pack_conv_weight": (_i, [_i, _vp, _i, _i, _vp, _vp]),
     "dm_conv_stats_partials": (_i, [_i, _i, _i]),
+    "dm_debug_lowres_taps": (None, [_vp]),
     "dm_groupnorm_silu": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "dm_conv2d": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i, _vp, _vp,
                        _i, _i, _i, _vp]),

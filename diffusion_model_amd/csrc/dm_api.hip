@@ -7,6 +7,7 @@
 #include "dm_kernels_x6.hip"
 #include "dm_kernels_init5.hip"
 #include "dm_kernels_generic.hip"
+#include "dm_kernels_lowres.hip"
 #include "../../include/dm_sampler.h"
 
 #include <hip/hip_runtime.h>
@@ -483,6 +484,7 @@ struct dm_unet {
   size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb, o_b0w, o_b3w, o_b0x, o_b3x;
   size_t o_i5w;        // init_conv composed with down1.conv1: nine weight sets (init5_kernel)
   int init5;           // 1: that composition replaces the two layers where the tile geometry allows (env DM_INIT5, default 1)
+  int lowres;          // 1: the fused low-resolution kernel where it applies (env DM_LOWRES, default 1; read when the handle is created)
   int fast;            // C in {64,128,256,512}, in/out channels <= 4: the tuned kernels apply (to power-of-two image sides);
                        // otherwise every geometry runs on the any-geometry kernels (dm_kernels_generic.hip)
   size_t total;
@@ -864,6 +866,57 @@ int unet_body_generic(const dm_unet* m, const float* P, const float* x, float* e
   return launch_gfinal(w.A0, w.SA, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H * W, C, m->Cout, s);
 }
 
+float* g_lowres_taps = nullptr;  // tests only (dm_debug_lowres_taps): where the fused kernel also writes its inner block outputs
+
+// The fused low-resolution kernel (dm_kernels_lowres.hip) covers the 32x32 model with 64 channels in fp32 with the
+// three-term split-bf16 weight forms; a property of the model and the image size only, never of the batch.
+bool uses_lowres(const dm_unet* m, int H, int W) {
+  return m->lowres && tuned_geometry(m, H, W) && !m->bf16 && !m->attn && m->C == 64 && H == 32 && W == 32 && (m->x6 & 31) == 7;
+}
+
+int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float* st2, int pin2, float cnt2, const float* heads,
+                  int heads_img_stride, int heads_step_stride, const int* step_ptr, int step_off, float* d2, float* u2, int B,
+                  hipStream_t s) {
+  LowresArgs a;
+  memset(&a, 0, sizeof a);
+  auto layer = [&](size_t w, size_t bias, size_t gamma, size_t beta, bool norm, int temb_k) {
+    LrLayer L;
+    L.w = reinterpret_cast<const bf16_t*>(P + w); L.bias = P + bias;
+    L.gamma = norm ? P + gamma : nullptr; L.beta = norm ? P + beta : nullptr; L.temb_k = temb_k;
+    return L;
+  };
+  const BlockOff &d2b = m->blk[1], &d3 = m->blk[2], &u1 = m->blk[3], &u2b = m->blk[4];
+  a.t2 = t2; a.st2 = st2; a.pin2 = pin2; a.cnt2 = cnt2; a.g2 = P + d2b.g2; a.b2 = P + d2b.b2;
+  a.d2t = layer(d2b.trx, d2b.trb, 0, 0, false, -1);
+  a.d3c1 = layer(d3.c1x, d3.c1b, d3.g1, d3.b1, true, 2);
+  a.d3c2 = layer(d3.c2x, d3.c2b, d3.g2, d3.b2, true, -1);
+  a.d3t = layer(d3.trx, d3.trb, 0, 0, false, -1);
+  a.b0 = layer(m->o_b0x, m->o_b0b, m->o_bg, m->o_bb, true, -1);
+  a.b3 = layer(m->o_b3x, m->o_b3b, 0, 0, false, -1);
+  a.u1c1 = layer(u1.c1x, u1.c1b, u1.g1, u1.b1, true, 3);
+  a.u1c2 = layer(u1.c2x, u1.c2b, u1.g2, u1.b2, true, -1);
+  a.u1t = layer(u1.trx, u1.trb, 0, 0, false, -1);
+  a.u2c1 = layer(u2b.c1x, u2b.c1b, u2b.g1, u2b.b1, true, 4);
+  a.u2c2 = layer(u2b.c2x, u2b.c2b, u2b.g2, u2b.b2, true, -1);
+  a.u2t = layer(u2b.trx, u2b.trb, 0, 0, false, -1);
+  a.heads = heads; a.heads_img_stride = heads_img_stride; a.heads_step_stride = heads_step_stride;
+  a.step_ptr = step_ptr; a.step_off = step_off; a.d2 = d2; a.u2 = u2; a.B = B;
+  a.taps = g_lowres_taps;
+  static bool attr_done[DM_MAX_DEVICES] = {false};
+  const int dev = current_device();
+  if (!attr_done[dev]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done[dev] = true;
+  }
+  unsigned grid = 2u * cu_count(dev);  // persistent: two workgroups per CU (60 KB of LDS each), images n, n + grid, ...
+  if (grid > (unsigned)B) grid = (unsigned)B;
+  // algorithmic work of the twelve layers: 25,231,360 multiply-adds per image
+  ProfScope ps(DM_K_LOWRES, s, 2.0 * 25231360.0 * B, 4.0 * B * (2.0 * 16 * 16 * 64 + 2.0 * 8 * 8 * 64) + 6.0 * 12.6 * 64 * 64 * 9);
+  hipLaunchKernelGGL(lowres_fused_kernel, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // One denoiser evaluation (everything after the time embedding): model.py:135-151.
 // heads: [.., 6, C] table; heads_img_stride = 6*C when every image has its own timestep
 // (training-style [B] t) else 0; in the sampling loop the table is indexed by the step
@@ -910,7 +963,8 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   const int xmode = (x6 & 16) ? 2 : 1;  // bit 4: two-term splits (three MFMAs per product; about 7x the fp32 rounding error) - opt-in
   auto x3 = [&](int h, int ww) { return h * ww >= 16 && ((x6 & 8) || ((x6 & 4) && (h < 8 || ww < 8))); };
   auto k3 = [&](int h, int ww) { return (!m->bf16 && !x3(h, ww) && h >= 8 && ww >= 8) ? 5 : 0; };
-  auto block = [&](int k, const float* in1, const float* in2, int h, int ww, bool up, float* out, float* out_stats) -> int {
+  auto block = [&](int k, const float* in1, const float* in2, int h, int ww, bool up, float* out, float* out_stats,
+                   bool convs_only = false) -> int {
     const BlockOff& o = m->blk[k];
     const int kd = k3(h, ww);
     const bool xs = x3(h, ww);
@@ -933,6 +987,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     c.temb = heads + (size_t)k * C; c.temb_stride = heads_img_stride; c.temb_step_stride = heads_step_stride;
     c.step_ptr = step_ptr; c.step_off = step_off;
     if (launch_conv(c, s)) return 1;
+    if (convs_only) return 0;  // (the transform belongs to the fused low-resolution kernel)
     const int kdn = (!m->bf16 && (h / 2) * (ww / 2) >= 256) ? 6 : 1;  // stride-2 conv: 128-pixel tiles from 16x16 outputs up
     const bool xt = up ? ((x6 & 2) && h * ww >= 16) : ((x6 & 1) && (h / 2) * (ww / 2) >= 16);
     base(up ? 2 : kdn, w.T2, C, nullptr, 0, xt ? o.trx : o.tr, o.trb, out, out_stats, h, ww);
@@ -941,6 +996,18 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     return launch_conv(c, s);
   };
   if (block(0, w.A0, nullptr, H, W, false, w.D1, nullptr)) return 1;
+  if (uses_lowres(m, H, W)) {
+    // everything at and below 8x8 pixels - down2.transform ... up2.transform, twelve layers - in ONE launch with the
+    // activations in LDS (dm_kernels_lowres.hip); chosen by geometry only, so results do not depend on the batch
+    if (block(1, w.D1, nullptr, H / 2, W / 2, false, nullptr, nullptr, true)) return 1;
+    const ConvGeo pg = conv_geo(k3(H / 2, W / 2), H / 2, W / 2, C);
+    if (launch_lowres(m, P, w.T2, w.SB, pg.pout, pg.cnt_out, heads, heads_img_stride, heads_step_stride, step_ptr, step_off, w.D2, w.U2, B, s))
+      return 1;
+    if (block(5, w.U2, w.D1, H / 2, W / 2, true, w.A0, w.SA)) return 1;
+    const ConvGeo pf = conv_geo(2, H / 2, W / 2, C);
+    return launch_final(w.A0, m->bf16, w.SA, pf.pout, pf.cnt_out, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H, W, C,
+                        m->Cout, s);
+  }
   if (block(1, w.D1, nullptr, H / 2, W / 2, false, w.D2, m->attn ? w.SA : nullptr)) return 1;
   if (m->attn) {
     const ConvGeo pg = conv_geo((!m->bf16 && (H / 4) * (W / 4) >= 256) ? 6 : 1, H / 2, W / 2, C);  // down2.transform
@@ -1109,6 +1176,7 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
   m->fast = fast ? 1 : 0;
   m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 31 : DM_X6_DEFAULT;
   m->init5 = getenv("DM_INIT5") ? (atoi(getenv("DM_INIT5")) != 0) : 1;
+  m->lowres = getenv("DM_LOWRES") ? (atoi(getenv("DM_LOWRES")) != 0) : 1;
   const int C = m->C, E = m->E;
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
@@ -1505,6 +1573,8 @@ int dm_class_embed(const float* table_dev, int num_rows, int E, const float* w1,
 #ifdef DM_STAMPS
 void dm_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
 #endif
+
+void dm_debug_lowres_taps(float* taps_dev) { g_lowres_taps = taps_dev; }
 
 size_t dm_conv_packed_floats(int kind, int cin, int cout) { return conv_packed_floats(kind, cin, cout); }
 

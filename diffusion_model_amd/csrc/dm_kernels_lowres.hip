@@ -1,0 +1,495 @@
+// dm_kernels_lowres.hip — the levels at and below 8x8 pixels of the 32x32 model in ONE launch.
+//
+// model.py:139-147 between down2's second GroupNorm and up2's output: down2.transform (16x16 -> 8x8), down3 (conv1, conv2 at
+// 8x8, transform 8x8 -> 4x4), the bottleneck pair, up1 (conv1 over cat[bott, down3], conv2 at 4x4, ConvTranspose 4x4 -> 8x8),
+// up2 (conv1 over cat[up1, down2], conv2 at 8x8, ConvTranspose 8x8 -> 16x16): twelve convolutions, seven GroupNorm+SiLU
+// (+ time embedding) transforms.  As separate launches each of them is one latency-bound tile per workgroup (64 images: 32
+// or 16 workgroups on a 256-CU chip; 219 of the 432 us of an ancestral-1000 step at B = 64).  Here ONE workgroup takes ONE
+// image through all twelve layers: every activation between the 16x16 input and the 16x16 output stays on the CU - as the
+// three-bf16-term planes the next layer's matrix instructions read, in LDS - the GroupNorm statistics are whole-image sums
+// taken from the accumulator registers, and the transform of a layer's output runs in the registers that hold it.
+// Only down2's 8x8 output makes a round trip through global memory (16 KiB per image: it is needed again, as the skip input
+// of up2.conv1, when its LDS planes have long been reused).
+//
+// Arithmetic: conv_x6_kernel's - every fp32 operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 per product, small
+// terms first, fp32 accumulation (fp32-equivalent accuracy) -, weights from the model's split-bf16
+// packs ([split][parity][tap][Cin/16][Cout/32][64 lanes][8]), swapped operands (weights as A, pixels as B) so a lane holds
+// one pixel and four runs of four consecutive channels.  Workgroup = 4 waves: at 8x8 as 2 (pixel halves) x 2 (channel
+// halves); at 4x4 (16 pixels: half a 32-row block) the pixel-half index splits K instead and the two partial sums meet
+// through LDS, or - transposed conv 4x4 -> 8x8 - it splits the four output parities.
+// Chosen by the layer geometry only (C = 64, 32x32 images, fp32, no attention), never by the batch size: per-image results
+// do not depend on the batch an image rides in, so multi-GPU shards stay bit-identical to the unsharded run.
+#pragma once
+#include "dm_kernels_x6.hip"
+
+struct LrLayer {
+  const bf16_t* w;     // split-bf16 packed weights
+  const float* bias;   // [64]
+  const float* gamma;  // GroupNorm applied to this layer's OUTPUT (null: the consumer reads it raw)
+  const float* beta;
+  int temb_k;          // time-embedding head added after that GroupNorm + SiLU (block index 0..5), -1: none
+};
+
+struct LowresArgs {
+  const float* t2;       // [B,16,16,64] raw output of down2.conv2
+  const float* st2;      // its GroupNorm statistics partials [B][pin2][8][2]
+  int pin2; float cnt2;
+  const float* g2; const float* b2;  // down2.bnorm2
+  LrLayer d2t, d3c1, d3c2, d3t, b0, b3, u1c1, u1c2, u1t, u2c1, u2c2, u2t;
+  const float* heads; int heads_img_stride, heads_step_stride;  // [.., 6, 64] time-embedding heads (see unet_body)
+  const int* step_ptr; int step_off;
+  float* d2;             // [B,8,8,64] scratch: down2's raw output (skip input of up2.conv1)
+  float* u2;             // [B,16,16,64] up2's output
+  float* taps;           // null, or (tests) [B][2048 + 4096] raw fp32 NHWC: down3's output (4x4x64), the bottleneck's (4x4x64), up1's (8x8x64)
+  int B;
+};
+
+namespace lr {
+constexpr int RSB = 72;            // bf16 elements per pixel row: 64 channels + 8 of skew (144 B)
+constexpr int PL = 100 * RSB;      // plane stride of the main buffer P: 10x10 halo pixels / 4 phases x 5x5 / 9x9 phase
+constexpr int PL4 = 36 * RSB;      // plane stride of the 4x4-level buffers: 6x6 halo pixels
+constexpr int P_BYTES = 3 * PL * 2;      // 43,200
+constexpr int Q_BYTES = 3 * PL4 * 2;     // 15,552
+constexpr int X_OFF = 2 * Q_BYTES;       // K-split exchange area inside P (behind E and F): 8 KiB
+constexpr int SM_FLOATS = 256;           // GroupNorm tables of the input stage + reduction words
+constexpr int LDS_BYTES = P_BYTES + Q_BYTES + SM_FLOATS * 4;
+constexpr size_t JS = 1024;        // weight elements per (16 input channels, 64 output channels)
+
+// acc += sum_{t < ntaps} sum_{j < NJ} W[wt(t)][j] (A operand) x plane pixels at aoff(t), channels 16 j .. (B operand), for the
+// three split terms: six MFMAs per (tap, 16 channels), one memory instruction (LDS read of the next pixel fragment or L2 read
+// of the next weight fragment) behind each of them.  ap: the lane's fragment address in plane 0 at tap offset 0 (+ first
+// channel slab); wp: the wave's weight fragment base (+ first channel slab); tapf(t, aoff, wt).
+template <int NJ, class F>
+__device__ __forceinline__ void kseg(f32x16& acc, const bf16_t* ap, int pl, const bf16_t* wp, size_t tapstride, size_t split_off,
+                                     unsigned lane16, int ntaps, F tapf) {
+  static_assert(NJ == 2 || NJ == 4, "even slab count: the double buffer alternates per slab");
+  uint4 a[2][3], b[2][3];
+  int aoff, wt;
+  tapf(0, aoff, wt);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    a[0][s] = *reinterpret_cast<const uint4*>(ap + s * pl + aoff);
+    b[0][s] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wp + s * split_off + (size_t)wt * tapstride) + lane16);
+  }
+#pragma unroll 1
+  for (int t = 0; t < ntaps; ++t) {
+    int aoffn, wtn;
+    tapf(t + 1 < ntaps ? t + 1 : t, aoffn, wtn);  // (clamped: the last prefetch re-reads valid data, unused)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = j & 1, nx = c ^ 1;
+      const bool wrap = j + 1 == NJ;
+      const bf16_t* an = ap + (wrap ? aoffn : aoff + (j + 1) * 16);
+      const bf16_t* wn = wp + (wrap ? (size_t)wtn * tapstride : (size_t)wt * tapstride + (size_t)(j + 1) * JS);
+      const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, a[c][0]), a2 = __builtin_bit_cast(bf16x8_t, a[c][1]), a3 = __builtin_bit_cast(bf16x8_t, a[c][2]);
+      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, b[c][0]), b2 = __builtin_bit_cast(bf16x8_t, b[c][1]), b3 = __builtin_bit_cast(bf16x8_t, b[c][2]);
+      __builtin_amdgcn_sched_barrier(0);
+      // pixel terms a (B operand), weight terms b (A operand); products a1b3, a2b2, a1b2, a3b1, a2b1, a1b1 (small terms first)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1, acc, 0, 0, 0);
+      a[nx][0] = *reinterpret_cast<const uint4*>(an);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2, acc, 0, 0, 0);
+      a[nx][1] = *reinterpret_cast<const uint4*>(an + pl);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1, acc, 0, 0, 0);
+      a[nx][2] = *reinterpret_cast<const uint4*>(an + 2 * pl);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3, acc, 0, 0, 0);
+      b[nx][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wn + 2 * split_off) + lane16);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2, acc, 0, 0, 0);
+      b[nx][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wn + split_off) + lane16);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc, 0, 0, 0);
+      b[nx][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wn) + lane16);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    aoff = aoffn; wt = wtn;
+  }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16& acc) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+}
+
+// lane l of wave (., wn) holds channels wn*32 + 8k + 4(l>>5) + e in acc[4k + e]
+__device__ __forceinline__ void add_bias(f32x16& acc, const float* bias, int cb) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 bv = *reinterpret_cast<const float4*>(bias + cb + 8 * k);
+    acc[4 * k] += bv.x; acc[4 * k + 1] += bv.y; acc[4 * k + 2] += bv.z; acc[4 * k + 3] += bv.w;
+  }
+}
+
+// sum over the 64 lanes of a wave, result in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __shfl_xor(v, 32, 64);
+  v += __shfl_xor(v, 16, 64);
+  return dm_row16_sum(v);
+}
+
+// GroupNorm(8) + SiLU (+ time embedding) of a layer's output IN the accumulator registers.  Statistics: whole-image (mean, M2)
+// per group, two passes over the registers; `valid`: this lane holds a pixel; NW: waves that share a group's pixels (2 at
+// 8x8: the pixel halves meet through `red` and two barriers; 1 at 4x4: lanes only, no barrier).  Every wave of the
+// workgroup must call the NW = 2 form.  inv_cnt = 1 / (pixels x 8 channels).
+template <int NW>
+__device__ __forceinline__ void gn_silu_regs(f32x16& acc, bool valid, float inv_cnt, const float* gamma, const float* beta,
+                                             const float* temb, int cb, float* red, int wave, int wn) {
+  // affine parameters and time embedding of this lane's 16 channels: issued first, they arrive while the sums are taken
+  float4 gm[4], bt[4], te[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    gm[k] = *reinterpret_cast<const float4*>(gamma + cb + 8 * k);
+    bt[k] = *reinterpret_cast<const float4*>(beta + cb + 8 * k);
+    te[k] = temb ? *reinterpret_cast<const float4*>(temb + cb + 8 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float mu[4], m2[4];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    float val[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float sm = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dlt = acc[4 * k + e] - (pass ? mu[k] : 0.f);
+        sm += pass ? dlt * dlt : dlt;
+      }
+      val[k] = wave_sum(valid ? sm : 0.f);
+    }
+    if (NW == 2) {
+      float* rr = red + pass * 16;
+      if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rr[wave * 4 + k] = val[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) val[k] = rr[wn * 4 + k] + rr[(2 + wn) * 4 + k];  // pixel halves wm = 0, 1 (wave = wm*2 + wn)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (pass == 0) mu[k] = val[k] * inv_cnt;
+      else m2[k] = val[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float rstd = rsqrtf(m2[k] * inv_cnt + DM_GN_EPS);
+    const float4 sc = make_float4(rstd * gm[k].x, rstd * gm[k].y, rstd * gm[k].z, rstd * gm[k].w);
+    const float4 sh = make_float4(bt[k].x - mu[k] * sc.x, bt[k].y - mu[k] * sc.y, bt[k].z - mu[k] * sc.z, bt[k].w - mu[k] * sc.w);
+    const float4 w = make_float4(fmaf(acc[4 * k], sc.x, sh.x), fmaf(acc[4 * k + 1], sc.y, sh.y), fmaf(acc[4 * k + 2], sc.z, sh.z),
+                                 fmaf(acc[4 * k + 3], sc.w, sh.w));
+    const float4 o = dm_silu_add4(w, te[k]);
+    acc[4 * k] = o.x; acc[4 * k + 1] = o.y; acc[4 * k + 2] = o.z; acc[4 * k + 3] = o.w;
+  }
+}
+
+// the lane's 16 values -> three bf16 planes at pixel index pix of a plane buffer (plane stride pl)
+__device__ __forceinline__ void put_planes(const f32x16& acc, bf16_t* buf, int pl, int pix, int cb) {
+  bf16_t* q = buf + pix * RSB + cb;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint2 s1, s2, s3;
+    dm_split3(acc[4 * k], acc[4 * k + 1], s1.x, s2.x, s3.x);
+    dm_split3(acc[4 * k + 2], acc[4 * k + 3], s1.y, s2.y, s3.y);
+    *reinterpret_cast<uint2*>(q + 8 * k) = s1;
+    *reinterpret_cast<uint2*>(q + 8 * k + pl) = s2;
+    *reinterpret_cast<uint2*>(q + 8 * k + 2 * pl) = s3;
+  }
+}
+
+// the lane's 16 values as fp32 at q (+ 8k per run)
+__device__ __forceinline__ void put_f32(const f32x16& acc, float* q) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(q + 8 * k) = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+}
+
+// zero the given pixel rows (all three planes) of a plane buffer: idx -> pixel index through f
+template <class F>
+__device__ __forceinline__ void zero_pixels(bf16_t* buf, int pl, int npix, F pixf) {
+  for (int i = threadIdx.x; i < npix * 27; i += 256) {  // 3 planes x 9 uint4 per pixel row
+    const int pp = i / 27, r = i - pp * 27, s = r / 9, u = r - s * 9;
+    *reinterpret_cast<uint4*>(buf + s * pl + pixf(pp) * RSB + u * 8) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+// halo ring of an N x N layout with an (N-2) x (N-2) interior
+template <int N>
+__device__ __forceinline__ void zero_ring(bf16_t* buf, int pl) {
+  zero_pixels(buf, pl, 4 * (N - 1), [](int i) {
+    const int side = i / (N - 1), k = i - side * (N - 1);
+    return side == 0 ? k : side == 1 ? (N - 1) * N + 1 + k : side == 2 ? (1 + k) * N : k * N + N - 1;
+  });
+}
+}  // namespace lr
+
+__global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p) {
+  using namespace lr;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bf16_t* P = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* D3p = P + 3 * PL;
+  float* sm = reinterpret_cast<float*>(D3p + 3 * PL4);
+  bf16_t* E = P;                    // 4x4-level buffers live in P while the 8x8 level does not need it
+  bf16_t* Fb = P + 3 * PL4;
+  float* X = reinterpret_cast<float*>(reinterpret_cast<char*>(P) + X_OFF);
+  float* s_scale = sm;              // [64] input stage only
+  float* s_shift = sm + 64;         // [64]
+  float* red = sm + 128;            // [32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+  const int wn_s = __builtin_amdgcn_readfirstlane(wn), wm_s = __builtin_amdgcn_readfirstlane(wm);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int cb = wn * 32 + 4 * h;   // first channel of the lane's run 0
+  const int step = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
+  // 8x8 layers: this lane's pixel; 4x4 layers: pixel l31 & 15 (lanes 16-31 of each half duplicate it, results unused)
+  const int m8 = wm * 32 + l31, y8 = m8 >> 3, x8 = m8 & 7;
+  const int m4 = l31 & 15, y4 = m4 >> 2, x4 = m4 & 3;
+  const bool v4 = l31 < 16;
+  const size_t TS64 = 4 * JS, TS128 = 8 * JS;  // tap strides for 64 / 128 input channels
+  const size_t wofs = (size_t)wn_s * 512;      // this wave's 32 output channels
+
+  zero_ring<6>(D3p, PL4);  // its halo is written here only; the interior is rewritten per image
+
+  for (int n = blockIdx.x; n < p.B; n += gridDim.x) {
+    const float* hd = p.heads + (size_t)step * p.heads_step_stride + (size_t)n * p.heads_img_stride;
+    auto temb_of = [&](const LrLayer& L) { return L.temb_k >= 0 ? hd + L.temb_k * 64 : (const float*)nullptr; };
+    f32x16 acc;
+
+    // ================= A: down2.transform, Conv2d 4x4 s2 p1, 16x16 -> 8x8 (model.py:46,64) =================
+    // input = SiLU(GroupNorm(t2)) (down2.bnorm2; no time embedding after the second norm), staged one input phase (row parity a,
+    // column parity b) at a time: plane pixel (Y, X), 0..8, = input pixel (2Y - a, 2X - b); taps ky = 2ty + 1 - a, kx = 2tx + 1 - b
+    if (tid < 64) {
+      const int c = tid;
+      const float* st = p.st2 + ((size_t)n * p.pin2 * DM_GROUPS + (c >> 3)) * 2;
+      float msum = 0.f, m2 = 0.f, dev = 0.f;
+      for (int q = 0; q < p.pin2; ++q) msum += st[q * DM_GROUPS * 2];
+      const float mean = msum / (float)p.pin2;
+      for (int q = 0; q < p.pin2; ++q) {
+        const float dq = st[q * DM_GROUPS * 2] - mean;
+        m2 += st[q * DM_GROUPS * 2 + 1];
+        dev += dq * dq;
+      }
+      const float var = (m2 + p.cnt2 * dev) / (p.cnt2 * (float)p.pin2);
+      const float sc = rsqrtf(var + DM_GN_EPS) * p.g2[c];
+      s_scale[c] = sc;
+      s_shift[c] = p.b2[c] - mean * sc;
+    }
+    zero_acc(acc);
+    const float* src = p.t2 + (size_t)n * 16 * 16 * 64;
+    for (int ph = 0; ph < 4; ++ph) {
+      const int pa = ph >> 1, pb = ph & 1;
+      __syncthreads();  // tables ready / the previous phase's (previous image's) reads of P are done
+      float4 v0[3], v1[3];
+      bool inb[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int idx = tid + 256 * u;
+        const int pix = min(idx >> 3, 80), c8 = idx & 7;
+        const int Y = pix / 9, Xc = pix - Y * 9;
+        const int iy = 2 * Y - pa, ix = 2 * Xc - pb;
+        inb[u] = (unsigned)iy < 16u && (unsigned)ix < 16u;
+        const float* q = src + ((min(max(iy, 0), 15) * 16 + min(max(ix, 0), 15)) * 64 + c8 * 8);
+        v0[u] = *reinterpret_cast<const float4*>(q);
+        v1[u] = *reinterpret_cast<const float4*>(q + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int idx = tid + 256 * u;
+        if (idx < 81 * 8) {
+          const int pix = idx >> 3, c8 = idx & 7;
+          float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+          if (inb[u]) {
+            const float4 sc0 = *reinterpret_cast<const float4*>(s_scale + c8 * 8), sc1 = *reinterpret_cast<const float4*>(s_scale + c8 * 8 + 4);
+            const float4 sh0 = *reinterpret_cast<const float4*>(s_shift + c8 * 8), sh1 = *reinterpret_cast<const float4*>(s_shift + c8 * 8 + 4);
+            w0 = dm_silu_add4(make_float4(fmaf(v0[u].x, sc0.x, sh0.x), fmaf(v0[u].y, sc0.y, sh0.y), fmaf(v0[u].z, sc0.z, sh0.z), fmaf(v0[u].w, sc0.w, sh0.w)), make_float4(0.f, 0.f, 0.f, 0.f));
+            w1 = dm_silu_add4(make_float4(fmaf(v1[u].x, sc1.x, sh1.x), fmaf(v1[u].y, sc1.y, sh1.y), fmaf(v1[u].z, sc1.z, sh1.z), fmaf(v1[u].w, sc1.w, sh1.w)), make_float4(0.f, 0.f, 0.f, 0.f));
+          }
+          uint4 s1, s2, s3;
+          dm_split3(w0.x, w0.y, s1.x, s2.x, s3.x);
+          dm_split3(w0.z, w0.w, s1.y, s2.y, s3.y);
+          dm_split3(w1.x, w1.y, s1.z, s2.z, s3.z);
+          dm_split3(w1.z, w1.w, s1.w, s2.w, s3.w);
+          bf16_t* q = P + pix * RSB + c8 * 8;
+          *reinterpret_cast<uint4*>(q) = s1;
+          *reinterpret_cast<uint4*>(q + PL) = s2;
+          *reinterpret_cast<uint4*>(q + 2 * PL) = s3;
+        }
+      }
+      __syncthreads();
+      kseg<4>(acc, P + (y8 * 9 + x8) * RSB + 8 * h, PL, p.d2t.w + wofs, TS64, 16 * TS64, lane16, 4,
+              [&](int t, int& ao, int& wt) { ao = ((t >> 1) * 9 + (t & 1)) * RSB; wt = (2 * (t >> 1) + 1 - pa) * 4 + 2 * (t & 1) + 1 - pb; });
+    }
+    add_bias(acc, p.d2t.bias, cb);
+    {  // down2's output, raw: to global (skip input of up2.conv1, read back by this workgroup) and, as planes, the input of down3.conv1
+      float* q = p.d2 + ((size_t)n * 64 + m8) * 64 + cb;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(q + 8 * k) = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+    }
+    __syncthreads();  // every wave is done reading the phase planes
+    zero_ring<10>(P, PL);
+    put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
+
+    // ================= B, C: down3.conv1, down3.conv2, Conv2d 3x3 p1 at 8x8 (model.py:54-62) =================
+    const bf16_t* a8 = P + (y8 * 10 + x8) * RSB + 8 * h;
+    auto tap3_10 = [&](int t, int& ao, int& wt) { const int ty = t / 3; ao = (ty * 10 + t - 3 * ty) * RSB; wt = t; };
+    __syncthreads();
+    zero_acc(acc);
+    kseg<4>(acc, a8, PL, p.d3c1.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
+    add_bias(acc, p.d3c1.bias, cb);
+    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.d3c1.gamma, p.d3c1.beta, temb_of(p.d3c1), cb, red, wave, wn);
+    // (the two barriers inside: every wave is past its K loop, P may be rewritten; the halo ring stays zero)
+    put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
+    __syncthreads();
+    zero_acc(acc);
+    kseg<4>(acc, a8, PL, p.d3c2.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
+    add_bias(acc, p.d3c2.bias, cb);
+    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.d3c2.gamma, p.d3c2.beta, temb_of(p.d3c2), cb, red, wave, wn);
+    // output in the four-phase layout of the stride-2 conv: input pixel (y, x) = (2Y - a, 2X - b) -> plane (a, b) pixel (Y, X) of 5x5
+    {
+      const int pa = y8 & 1, pb = x8 & 1;
+      put_planes(acc, P, PL, (pa * 2 + pb) * 25 + ((y8 + pa) >> 1) * 5 + ((x8 + pb) >> 1), cb);
+      // padding: row Y = 4 of the planes with a = 0 (input row 8), row Y = 0 with a = 1 (input row -1); columns alike
+      zero_pixels(P, PL, 36, [](int i) {
+        const int ph = i / 9, k = i - ph * 9, a = ph >> 1, b = ph & 1;
+        const int Yp = a ? 0 : 4, Xp = b ? 0 : 4;
+        return ph * 25 + (k < 5 ? Yp * 5 + k : ((k - 5) + (Yp == 0 ? 1 : 0)) * 5 + Xp);
+      });
+    }
+
+    // ================= D: down3.transform, Conv2d 4x4 s2 p1, 8x8 -> 4x4: K split by input phase over the wave pairs =================
+    __syncthreads();
+    zero_acc(acc);
+    {
+      const bf16_t* ad = P + (y4 * 5 + x4) * RSB + 8 * h;
+      kseg<4>(acc, ad, PL, p.d3t.w + wofs, TS64, 16 * TS64, lane16, 8, [&](int t, int& ao, int& wt) {
+        const int ph = 2 * wm_s + (t >> 2), pa = ph >> 1, pb = ph & 1, ty = (t >> 1) & 1, tx = t & 1;
+        ao = (ph * 25 + ty * 5 + tx) * RSB;
+        wt = (2 * ty + 1 - pa) * 4 + 2 * tx + 1 - pb;
+      });
+    }
+    __syncthreads();  // P is dead: the 4x4-level buffers E, F and the exchange area take its place
+    if (wm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) X[(wn * 16 + r) * 64 + lane] = acc[r];
+    }
+    zero_ring<6>(E, PL4);
+    zero_ring<6>(Fb, PL4);
+    __syncthreads();
+    const int pix6 = (y4 + 1) * 6 + x4 + 1;
+    if (!wm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += X[(wn * 16 + r) * 64 + lane];
+      add_bias(acc, p.d3t.bias, cb);
+      if (v4) put_planes(acc, D3p, PL4, pix6, cb);  // down3's output, raw: input of bottleneck.0 and skip input of up1.conv1
+      if (p.taps && v4) put_f32(acc, p.taps + (size_t)n * 6144 + m4 * 64 + cb);
+    }
+
+    // ================= E..H: bottleneck.0, bottleneck.3, up1.conv1, up1.conv2, Conv2d 3x3 p1 at 4x4 =================
+    // 16 pixels: the pixel-half index wm splits K (channel slabs 2wm, 2wm+1 of every tap; up1.conv1: one input per half)
+    auto tap3_6 = [&](int t, int& ao, int& wt) { const int ty = t / 3; ao = (ty * 6 + t - 3 * ty) * RSB; wt = t; };
+    auto conv4 = [&](const bf16_t* in0, const bf16_t* in1, const LrLayer& L, bf16_t* out, int tap_off) {
+      __syncthreads();  // the input planes are complete; the exchange area is free
+      zero_acc(acc);
+      const int a4 = (y4 * 6 + x4) * RSB + 8 * h;
+      if (in1) kseg<4>(acc, (wm_s ? in1 : in0) + a4, PL4, L.w + wofs + (size_t)wm_s * 4 * JS, TS128, 9 * TS128, lane16, 9, tap3_6);
+      else kseg<2>(acc, in0 + a4 + wm_s * 32, PL4, L.w + wofs + (size_t)wm_s * 2 * JS, TS64, 9 * TS64, lane16, 9, tap3_6);
+      if (wm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X[(wn * 16 + r) * 64 + lane] = acc[r];
+      }
+      __syncthreads();
+      if (!wm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += X[(wn * 16 + r) * 64 + lane];
+        add_bias(acc, L.bias, cb);
+        if (L.gamma) gn_silu_regs<1>(acc, v4, 1.0f / 128.0f, L.gamma, L.beta, temb_of(L), cb, red, wave, wn);
+        if (v4) put_planes(acc, out, PL4, pix6, cb);
+        if (tap_off >= 0 && p.taps && v4) put_f32(acc, p.taps + (size_t)n * 6144 + tap_off + m4 * 64 + cb);
+      }
+    };
+    conv4(D3p, nullptr, p.b0, E, -1);
+    conv4(E, nullptr, p.b3, Fb, 1024);
+    conv4(Fb, D3p, p.u1c1, E, -1);
+    conv4(E, nullptr, p.u1c2, Fb, -1);
+
+    // ================= I: up1.transform, ConvTranspose2d 4x4 s2 p1, 4x4 -> 8x8: output parities 2wm, 2wm+1 per wave pair =================
+    // out[2y+py][2x+px] = sum over ty, tx in {0,1} of in[y-1+py+ty][x-1+px+tx] w[3-py-2ty][3-px-2tx] (packed per parity)
+    __syncthreads();
+    f32x16 acc1;
+    zero_acc(acc);
+    zero_acc(acc1);
+    {
+      const bf16_t* au = Fb + (y4 * 6 + x4) * RSB + 8 * h;
+      const int par0 = 2 * wm_s;
+      kseg<4>(acc, au, PL4, p.u1t.w + wofs, TS64, 16 * TS64, lane16, 4,
+              [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + (t & 1)) * RSB; wt = par0 * 4 + t; });
+      kseg<4>(acc1, au, PL4, p.u1t.w + wofs, TS64, 16 * TS64, lane16, 4,
+              [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + 1 + (t & 1)) * RSB; wt = (par0 + 1) * 4 + t; });
+    }
+    add_bias(acc, p.u1t.bias, cb);
+    add_bias(acc1, p.u1t.bias, cb);
+    if (p.taps && v4) {
+      put_f32(acc, p.taps + (size_t)n * 6144 + 2048 + ((2 * y4 + wm) * 8 + 2 * x4) * 64 + cb);
+      put_f32(acc1, p.taps + (size_t)n * 6144 + 2048 + ((2 * y4 + wm) * 8 + 2 * x4 + 1) * 64 + cb);
+    }
+    __syncthreads();  // every wave is done with F: P becomes the 10x10 layout again
+    zero_ring<10>(P, PL);
+    if (v4) {  // up1's output, raw: first input of up2.conv1 (parity py = wm, px = 0 / 1)
+      put_planes(acc, P, PL, (2 * y4 + wm + 1) * 10 + 2 * x4 + 1, cb);
+      put_planes(acc1, P, PL, (2 * y4 + wm + 1) * 10 + 2 * x4 + 2, cb);
+    }
+
+    // ================= J, K: up2.conv1 over cat[up1, down2] (model.py:147), up2.conv2, Conv2d 3x3 p1 at 8x8 =================
+    __syncthreads();
+    zero_acc(acc);
+    float4 d2v[2][2];  // down2's output comes back from global memory while the first half of K runs
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u;  // 64 pixels x 8 channel octets
+      const float* q = p.d2 + ((size_t)n * 64 + (idx >> 3)) * 64 + (idx & 7) * 8;
+      d2v[u][0] = *reinterpret_cast<const float4*>(q);
+      d2v[u][1] = *reinterpret_cast<const float4*>(q + 4);
+    }
+    kseg<4>(acc, a8, PL, p.u2c1.w + wofs, TS128, 9 * TS128, lane16, 9, tap3_10);
+    __syncthreads();  // the up1 planes are consumed
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + 256 * u, pix = idx >> 3, c8 = idx & 7;
+      uint4 s1, s2, s3;
+      dm_split3(d2v[u][0].x, d2v[u][0].y, s1.x, s2.x, s3.x);
+      dm_split3(d2v[u][0].z, d2v[u][0].w, s1.y, s2.y, s3.y);
+      dm_split3(d2v[u][1].x, d2v[u][1].y, s1.z, s2.z, s3.z);
+      dm_split3(d2v[u][1].z, d2v[u][1].w, s1.w, s2.w, s3.w);
+      bf16_t* q = P + (((pix >> 3) + 1) * 10 + (pix & 7) + 1) * RSB + c8 * 8;
+      *reinterpret_cast<uint4*>(q) = s1;
+      *reinterpret_cast<uint4*>(q + PL) = s2;
+      *reinterpret_cast<uint4*>(q + 2 * PL) = s3;
+    }
+    __syncthreads();
+    kseg<4>(acc, a8, PL, p.u2c1.w + wofs + 4 * JS, TS128, 9 * TS128, lane16, 9, tap3_10);
+    add_bias(acc, p.u2c1.bias, cb);
+    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.u2c1.gamma, p.u2c1.beta, temb_of(p.u2c1), cb, red, wave, wn);
+    put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
+    __syncthreads();
+    zero_acc(acc);
+    kseg<4>(acc, a8, PL, p.u2c2.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
+    add_bias(acc, p.u2c2.bias, cb);
+    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.u2c2.gamma, p.u2c2.beta, temb_of(p.u2c2), cb, red, wave, wn);
+    put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
+
+    // ================= L: up2.transform, ConvTranspose2d 4x4 s2 p1, 8x8 -> 16x16, four output parities from the planes =================
+    __syncthreads();
+    for (int par = 0; par < 4; ++par) {
+      const int py = par >> 1, px = par & 1;
+      zero_acc(acc);
+      kseg<4>(acc, a8, PL, p.u2t.w + wofs, TS64, 16 * TS64, lane16, 4,
+              [&](int t, int& ao, int& wt) { ao = ((py + (t >> 1)) * 10 + px + (t & 1)) * RSB; wt = par * 4 + t; });
+      add_bias(acc, p.u2t.bias, cb);
+      float* q = p.u2 + (((size_t)n * 16 + 2 * y8 + py) * 16 + 2 * x8 + px) * 64 + cb;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(q + 8 * k) = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+    }
+  }
+}

@@ -259,6 +259,10 @@ int dm_final_conv(const float* u_dev, const float* stats_dev, int pin, float cnt
                   const float* gamma_dev, const float* beta_dev, const float* w_dev,
                   const float* bias_dev, float* out_dev, int B, int H, int W, int C, int Cout,
                   void* stream);
+/* Test hook of the fused low-resolution kernel (dm_kernels_lowres.hip keeps the outputs of down3, the bottleneck and up1
+ * in LDS: model.py:140,143,146): while taps_dev != NULL every later forward that takes that kernel also writes them, raw
+ * fp32 NHWC, to taps_dev[B][6144] = down3 [4,4,64] | bottleneck [4,4,64] | up1 [8,8,64].  NULL switches it off. */
+void dm_debug_lowres_taps(float* taps_dev);
 int dm_conv2d(int kind, const float* x1_dev, int c1, const float* x2_dev, int c2,
               const float* packed_w_dev, const float* bias_dev, int cout,
               const float* stats_in_dev, int pin, float cnt_in, const float* gamma_dev,
