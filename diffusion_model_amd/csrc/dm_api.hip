@@ -902,6 +902,9 @@ int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float
   a.heads = heads; a.heads_img_stride = heads_img_stride; a.heads_step_stride = heads_step_stride;
   a.step_ptr = step_ptr; a.step_off = step_off; a.d2 = d2; a.u2 = u2; a.B = B;
   a.taps = g_lowres_taps;
+#ifdef DM_STAMPS
+  a.stamps = g_stamps;
+#endif
   static bool attr_done[DM_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {

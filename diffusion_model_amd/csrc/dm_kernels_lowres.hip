@@ -40,9 +40,18 @@ struct LowresArgs {
   const int* step_ptr; int step_off;
   float* d2;             // [B,8,8,64] scratch: down2's raw output (skip input of up2.conv1)
   float* u2;             // [B,16,16,64] up2's output
+#ifdef DM_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: s_memtime stamps [grid][32] at entry 2^20 (the conv kernels stamp the front of the buffer) of the phases of the workgroup's LAST image
+#endif
   float* taps;           // null, or (tests) [B][2048 + 4096] raw fp32 NHWC: down3's output (4x4x64), the bottleneck's (4x4x64), up1's (8x8x64)
   int B;
 };
+
+#ifdef DM_STAMPS
+#define LR_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(1 << 20) + (size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LR_STAMP(k) do {} while (0)
+#endif
 
 namespace lr {
 constexpr int RSB = 72;            // bf16 elements per pixel row: 64 channels + 8 of skew (144 B)
@@ -55,34 +64,45 @@ constexpr int SM_FLOATS = 256;           // GroupNorm tables of the input stage 
 constexpr int LDS_BYTES = P_BYTES + Q_BYTES + SM_FLOATS * 4;
 constexpr size_t JS = 1024;        // weight elements per (16 input channels, 64 output channels)
 
-// acc += sum_{t < ntaps} sum_{j < NJ} W[wt(t)][j] (A operand) x plane pixels at aoff(t), channels 16 j .. (B operand), for the
-// three split terms: six MFMAs per (tap, 16 channels), one memory instruction (LDS read of the next pixel fragment or L2 read
-// of the next weight fragment) behind each of them.  ap: the lane's fragment address in plane 0 at tap offset 0 (+ first
-// channel slab); wp: the wave's weight fragment base (+ first channel slab); tapf(t, aoff, wt).
-template <int NJ, class F>
+// acc += sum_{t < ntaps} sum_{j < 4} W[wt(t)][j] (A operand) x plane pixels at aoff(t), channels 16 j .. (B operand), for the
+// three split terms: six MFMAs per (tap, 16 channels), one memory instruction behind each of them - the LDS reads of the NEXT
+// slab's pixel fragments (double buffer) and the L2 reads of the NEXT TAP's weight fragments into the slots just consumed (24
+// MFMAs ahead: one slab ahead, ~200 cycles, does not cover an L2 hit).  ap: the lane's fragment address in plane 0 at tap
+// offset 0; wp: the wave's weight fragment base; tapf(t, aoff, wt): LDS offset and packed-weight tap of step t.
+template <class F>
 __device__ __forceinline__ void kseg(f32x16& acc, const bf16_t* ap, int pl, const bf16_t* wp, size_t tapstride, size_t split_off,
                                      unsigned lane16, int ntaps, F tapf) {
-  static_assert(NJ == 2 || NJ == 4, "even slab count: the double buffer alternates per slab");
-  uint4 a[2][3], b[2][3];
+  constexpr int NJ = 4;
+  // opaque copies: the fragment addresses are formed HERE, per call - left alone hipcc hoists the address arithmetic of all
+  // eighteen call sites out of the image loop and spills it (1.5 KB of scratch per lane)
+  int opq = 0;
+  asm volatile("" : "+v"(opq));
+  lane16 += (unsigned)opq;
+  ap += opq;
+  uint4 a[2][3], bq[NJ][3];
   int aoff, wt;
   tapf(0, aoff, wt);
+  {
+    const bf16_t* w0 = wp + (size_t)wt * tapstride;
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    a[0][s] = *reinterpret_cast<const uint4*>(ap + s * pl + aoff);
-    b[0][s] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wp + s * split_off + (size_t)wt * tapstride) + lane16);
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        bq[j][s] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w0 + s * split_off + (size_t)j * JS) + lane16);
   }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) a[0][s] = *reinterpret_cast<const uint4*>(ap + s * pl + aoff);
 #pragma unroll 1
   for (int t = 0; t < ntaps; ++t) {
     int aoffn, wtn;
     tapf(t + 1 < ntaps ? t + 1 : t, aoffn, wtn);  // (clamped: the last prefetch re-reads valid data, unused)
+    const bf16_t* wnext = wp + (size_t)wtn * tapstride;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = j & 1, nx = c ^ 1;
-      const bool wrap = j + 1 == NJ;
-      const bf16_t* an = ap + (wrap ? aoffn : aoff + (j + 1) * 16);
-      const bf16_t* wn = wp + (wrap ? (size_t)wtn * tapstride : (size_t)wt * tapstride + (size_t)(j + 1) * JS);
+      const bf16_t* an = ap + ((j + 1 == NJ) ? aoffn : aoff + (j + 1) * 16);
       const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, a[c][0]), a2 = __builtin_bit_cast(bf16x8_t, a[c][1]), a3 = __builtin_bit_cast(bf16x8_t, a[c][2]);
-      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, b[c][0]), b2 = __builtin_bit_cast(bf16x8_t, b[c][1]), b3 = __builtin_bit_cast(bf16x8_t, b[c][2]);
+      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, bq[j][0]), b2 = __builtin_bit_cast(bf16x8_t, bq[j][1]), b3 = __builtin_bit_cast(bf16x8_t, bq[j][2]);
       __builtin_amdgcn_sched_barrier(0);
       // pixel terms a (B operand), weight terms b (A operand); products a1b3, a2b2, a1b2, a3b1, a2b1, a1b1 (small terms first)
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1, acc, 0, 0, 0);
@@ -95,13 +115,13 @@ __device__ __forceinline__ void kseg(f32x16& acc, const bf16_t* ap, int pl, cons
       a[nx][2] = *reinterpret_cast<const uint4*>(an + 2 * pl);
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3, acc, 0, 0, 0);
-      b[nx][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wn + 2 * split_off) + lane16);
+      bq[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * split_off + (size_t)j * JS) + lane16);
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2, acc, 0, 0, 0);
-      b[nx][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wn + split_off) + lane16);
+      bq[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + split_off + (size_t)j * JS) + lane16);
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc, 0, 0, 0);
-      b[nx][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wn) + lane16);
+      bq[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
       __builtin_amdgcn_sched_barrier(0);
     }
     aoff = aoffn; wt = wtn;
@@ -256,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     const float* hd = p.heads + (size_t)step * p.heads_step_stride + (size_t)n * p.heads_img_stride;
     auto temb_of = [&](const LrLayer& L) { return L.temb_k >= 0 ? hd + L.temb_k * 64 : (const float*)nullptr; };
     f32x16 acc;
+    LR_STAMP(0);
 
     // ================= A: down2.transform, Conv2d 4x4 s2 p1, 16x16 -> 8x8 (model.py:46,64) =================
     // input = SiLU(GroupNorm(t2)) (down2.bnorm2; no time embedding after the second norm), staged one input phase (row parity a,
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
         }
       }
       __syncthreads();
-      kseg<4>(acc, P + (y8 * 9 + x8) * RSB + 8 * h, PL, p.d2t.w + wofs, TS64, 16 * TS64, lane16, 4,
+      kseg(acc, P + (y8 * 9 + x8) * RSB + 8 * h, PL, p.d2t.w + wofs, TS64, 16 * TS64, lane16, 4,
               [&](int t, int& ao, int& wt) { ao = ((t >> 1) * 9 + (t & 1)) * RSB; wt = (2 * (t >> 1) + 1 - pa) * 4 + 2 * (t & 1) + 1 - pb; });
     }
     add_bias(acc, p.d2t.bias, cb);
@@ -331,19 +352,21 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     zero_ring<10>(P, PL);
     put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
 
+    LR_STAMP(1);
     // ================= B, C: down3.conv1, down3.conv2, Conv2d 3x3 p1 at 8x8 (model.py:54-62) =================
     const bf16_t* a8 = P + (y8 * 10 + x8) * RSB + 8 * h;
     auto tap3_10 = [&](int t, int& ao, int& wt) { const int ty = t / 3; ao = (ty * 10 + t - 3 * ty) * RSB; wt = t; };
     __syncthreads();
     zero_acc(acc);
-    kseg<4>(acc, a8, PL, p.d3c1.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
+    kseg(acc, a8, PL, p.d3c1.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
     add_bias(acc, p.d3c1.bias, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.d3c1.gamma, p.d3c1.beta, temb_of(p.d3c1), cb, red, wave, wn);
     // (the two barriers inside: every wave is past its K loop, P may be rewritten; the halo ring stays zero)
     put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
+    LR_STAMP(2);
     __syncthreads();
     zero_acc(acc);
-    kseg<4>(acc, a8, PL, p.d3c2.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
+    kseg(acc, a8, PL, p.d3c2.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
     add_bias(acc, p.d3c2.bias, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.d3c2.gamma, p.d3c2.beta, temb_of(p.d3c2), cb, red, wave, wn);
     // output in the four-phase layout of the stride-2 conv: input pixel (y, x) = (2Y - a, 2X - b) -> plane (a, b) pixel (Y, X) of 5x5
@@ -358,12 +381,13 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       });
     }
 
+    LR_STAMP(3);
     // ================= D: down3.transform, Conv2d 4x4 s2 p1, 8x8 -> 4x4: K split by input phase over the wave pairs =================
     __syncthreads();
     zero_acc(acc);
     {
       const bf16_t* ad = P + (y4 * 5 + x4) * RSB + 8 * h;
-      kseg<4>(acc, ad, PL, p.d3t.w + wofs, TS64, 16 * TS64, lane16, 8, [&](int t, int& ao, int& wt) {
+      kseg(acc, ad, PL, p.d3t.w + wofs, TS64, 16 * TS64, lane16, 8, [&](int t, int& ao, int& wt) {
         const int ph = 2 * wm_s + (t >> 2), pa = ph >> 1, pb = ph & 1, ty = (t >> 1) & 1, tx = t & 1;
         ao = (ph * 25 + ty * 5 + tx) * RSB;
         wt = (2 * ty + 1 - pa) * 4 + 2 * tx + 1 - pb;
@@ -386,15 +410,17 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       if (p.taps && v4) put_f32(acc, p.taps + (size_t)n * 6144 + m4 * 64 + cb);
     }
 
+    LR_STAMP(4);
     // ================= E..H: bottleneck.0, bottleneck.3, up1.conv1, up1.conv2, Conv2d 3x3 p1 at 4x4 =================
-    // 16 pixels: the pixel-half index wm splits K (channel slabs 2wm, 2wm+1 of every tap; up1.conv1: one input per half)
+    // 16 pixels: the pixel-half index wm splits K (taps 0..4 | 5..8; up1.conv1: one input per half)
     auto tap3_6 = [&](int t, int& ao, int& wt) { const int ty = t / 3; ao = (ty * 6 + t - 3 * ty) * RSB; wt = t; };
     auto conv4 = [&](const bf16_t* in0, const bf16_t* in1, const LrLayer& L, bf16_t* out, int tap_off) {
       __syncthreads();  // the input planes are complete; the exchange area is free
       zero_acc(acc);
       const int a4 = (y4 * 6 + x4) * RSB + 8 * h;
-      if (in1) kseg<4>(acc, (wm_s ? in1 : in0) + a4, PL4, L.w + wofs + (size_t)wm_s * 4 * JS, TS128, 9 * TS128, lane16, 9, tap3_6);
-      else kseg<2>(acc, in0 + a4 + wm_s * 32, PL4, L.w + wofs + (size_t)wm_s * 2 * JS, TS64, 9 * TS64, lane16, 9, tap3_6);
+      if (in1) kseg(acc, (wm_s ? in1 : in0) + a4, PL4, L.w + wofs + (size_t)wm_s * 4 * JS, TS128, 9 * TS128, lane16, 9, tap3_6);
+      else kseg(acc, in0 + a4, PL4, L.w + wofs, TS64, 9 * TS64, lane16, wm_s ? 4 : 5,
+                [&](int t, int& ao, int& wt) { tap3_6(t + 5 * wm_s, ao, wt); });
       if (wm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) X[(wn * 16 + r) * 64 + lane] = acc[r];
@@ -410,9 +436,13 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       }
     };
     conv4(D3p, nullptr, p.b0, E, -1);
+    LR_STAMP(5);
     conv4(E, nullptr, p.b3, Fb, 1024);
+    LR_STAMP(6);
     conv4(Fb, D3p, p.u1c1, E, -1);
+    LR_STAMP(7);
     conv4(E, nullptr, p.u1c2, Fb, -1);
+    LR_STAMP(8);
 
     // ================= I: up1.transform, ConvTranspose2d 4x4 s2 p1, 4x4 -> 8x8: output parities 2wm, 2wm+1 per wave pair =================
     // out[2y+py][2x+px] = sum over ty, tx in {0,1} of in[y-1+py+ty][x-1+px+tx] w[3-py-2ty][3-px-2tx] (packed per parity)
@@ -423,9 +453,9 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     {
       const bf16_t* au = Fb + (y4 * 6 + x4) * RSB + 8 * h;
       const int par0 = 2 * wm_s;
-      kseg<4>(acc, au, PL4, p.u1t.w + wofs, TS64, 16 * TS64, lane16, 4,
+      kseg(acc, au, PL4, p.u1t.w + wofs, TS64, 16 * TS64, lane16, 4,
               [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + (t & 1)) * RSB; wt = par0 * 4 + t; });
-      kseg<4>(acc1, au, PL4, p.u1t.w + wofs, TS64, 16 * TS64, lane16, 4,
+      kseg(acc1, au, PL4, p.u1t.w + wofs, TS64, 16 * TS64, lane16, 4,
               [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + 1 + (t & 1)) * RSB; wt = (par0 + 1) * 4 + t; });
     }
     add_bias(acc, p.u1t.bias, cb);
@@ -441,6 +471,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       put_planes(acc1, P, PL, (2 * y4 + wm + 1) * 10 + 2 * x4 + 2, cb);
     }
 
+    LR_STAMP(9);
     // ================= J, K: up2.conv1 over cat[up1, down2] (model.py:147), up2.conv2, Conv2d 3x3 p1 at 8x8 =================
     __syncthreads();
     zero_acc(acc);
@@ -452,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       d2v[u][0] = *reinterpret_cast<const float4*>(q);
       d2v[u][1] = *reinterpret_cast<const float4*>(q + 4);
     }
-    kseg<4>(acc, a8, PL, p.u2c1.w + wofs, TS128, 9 * TS128, lane16, 9, tap3_10);
+    kseg(acc, a8, PL, p.u2c1.w + wofs, TS128, 9 * TS128, lane16, 9, tap3_10);
     __syncthreads();  // the up1 planes are consumed
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -468,28 +499,31 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       *reinterpret_cast<uint4*>(q + 2 * PL) = s3;
     }
     __syncthreads();
-    kseg<4>(acc, a8, PL, p.u2c1.w + wofs + 4 * JS, TS128, 9 * TS128, lane16, 9, tap3_10);
+    kseg(acc, a8, PL, p.u2c1.w + wofs + 4 * JS, TS128, 9 * TS128, lane16, 9, tap3_10);
     add_bias(acc, p.u2c1.bias, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.u2c1.gamma, p.u2c1.beta, temb_of(p.u2c1), cb, red, wave, wn);
     put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
+    LR_STAMP(10);
     __syncthreads();
     zero_acc(acc);
-    kseg<4>(acc, a8, PL, p.u2c2.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
+    kseg(acc, a8, PL, p.u2c2.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
     add_bias(acc, p.u2c2.bias, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.u2c2.gamma, p.u2c2.beta, temb_of(p.u2c2), cb, red, wave, wn);
     put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
 
+    LR_STAMP(11);
     // ================= L: up2.transform, ConvTranspose2d 4x4 s2 p1, 8x8 -> 16x16, four output parities from the planes =================
     __syncthreads();
     for (int par = 0; par < 4; ++par) {
       const int py = par >> 1, px = par & 1;
       zero_acc(acc);
-      kseg<4>(acc, a8, PL, p.u2t.w + wofs, TS64, 16 * TS64, lane16, 4,
+      kseg(acc, a8, PL, p.u2t.w + wofs, TS64, 16 * TS64, lane16, 4,
               [&](int t, int& ao, int& wt) { ao = ((py + (t >> 1)) * 10 + px + (t & 1)) * RSB; wt = par * 4 + t; });
       add_bias(acc, p.u2t.bias, cb);
       float* q = p.u2 + (((size_t)n * 16 + 2 * y8 + py) * 16 + 2 * x8 + px) * 64 + cb;
 #pragma unroll
       for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(q + 8 * k) = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
     }
+    LR_STAMP(12);
   }
 }
