@@ -991,8 +991,13 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     c.step_ptr = step_ptr; c.step_off = step_off;
     if (launch_conv(c, s)) return 1;
     if (convs_only) return 0;  // (the transform belongs to the fused low-resolution kernel)
-    const int kdn = (!m->bf16 && (h / 2) * (ww / 2) >= 256) ? 6 : 1;  // stride-2 conv: 128-pixel tiles from 16x16 outputs up
+    int kdn = (!m->bf16 && (h / 2) * (ww / 2) >= 256) ? 6 : 1;  // stride-2 conv: 128-pixel tiles from 16x16 outputs up
     const bool xt = up ? ((x6 & 2) && h * ww >= 16) : ((x6 & 1) && (h / 2) * (ww / 2) >= 16);
+    // Small batches: when the 128-pixel tiles would leave half of the CUs without one, the split-bf16 stride-2 conv runs on
+    // 64-pixel tiles (twice the workgroups, half the K-loop latency each).  Its output carries no statistics and its K order
+    // (phase, tap, channel slab, split term) does not depend on the tile, so the result is bit-identical either way - the
+    // one place where the launch shape may follow the batch size without touching per-image results.
+    if (!up && xt && kdn == 6 && !out_stats && (size_t)B * ((h / 2) * (ww / 2) / 128) <= cu_count(current_device())) kdn = 1;
     base(up ? 2 : kdn, w.T2, C, nullptr, 0, xt ? o.trx : o.tr, o.trb, out, out_stats, h, ww);
     c.x6 = xt ? xmode : 0;
     with_tf(w.SB, kd, h, ww, o.g2, o.b2);

@@ -35,6 +35,8 @@ struct LowresArgs {
   const float* st2;      // its GroupNorm statistics partials [B][pin2][8][2]
   int pin2; float cnt2;
   const float* g2; const float* b2;  // down2.bnorm2
+  // layers in execution order: down2.transform, down3.conv1, down3.conv2, down3.transform, bottleneck.0, bottleneck.3,
+  // up1.conv1, up1.conv2, up1.transform, up2.conv1, up2.conv2, up2.transform
   LrLayer d2t, d3c1, d3c2, d3t, b0, b3, u1c1, u1c2, u1t, u2c1, u2c2, u2t;
   const float* heads; int heads_img_stride, heads_step_stride;  // [.., 6, 64] time-embedding heads (see unet_body)
   const int* step_ptr; int step_off;
@@ -59,72 +61,195 @@ constexpr int PL = 100 * RSB;      // plane stride of the main buffer P: 10x10 h
 constexpr int PL4 = 36 * RSB;      // plane stride of the 4x4-level buffers: 6x6 halo pixels
 constexpr int P_BYTES = 3 * PL * 2;      // 43,200
 constexpr int Q_BYTES = 3 * PL4 * 2;     // 15,552
-constexpr int X_OFF = 2 * Q_BYTES;       // K-split exchange area inside P (behind E and F): 8 KiB
-constexpr int SM_FLOATS = 256;           // GroupNorm tables of the input stage + reduction words
-constexpr int LDS_BYTES = P_BYTES + Q_BYTES + SM_FLOATS * 4;
+constexpr int X_OFF = 2 * Q_BYTES;       // 4x4 level: K-split exchange area inside P (behind E and F), 8 KiB
+constexpr int X8_BYTES = 16384;          // 8x8 level: K-split exchange area = the D3p buffer (dead outside the 4x4 level) + 832 B
+// small tables (floats): input-stage GroupNorm tables, reduction words, and every layer's bias / GroupNorm affine
+// parameters / time-embedding rows, loaded once per workgroup (time embedding: per image) so that no epilogue waits on L2
+constexpr int SM_SCALE = 0, SM_SHIFT = 64, SM_RED = 128, SM_BIAS = 192;   // bias [12][64]
+constexpr int SM_GAMMA = SM_BIAS + 12 * 64, SM_BETA = SM_GAMMA + 7 * 64, SM_TEMB = SM_BETA + 7 * 64;  // [7][64], [7][64], [3][64]
+constexpr int SM_FLOATS = SM_TEMB + 3 * 64;
+constexpr int LDS_BYTES = P_BYTES + X8_BYTES + SM_FLOATS * 4;
 constexpr size_t JS = 1024;        // weight elements per (16 input channels, 64 output channels)
+
+// A wave's weight stream of one layer: fragment base (its 32 output channels), tap stride, split-term stride.
+struct WS { const bf16_t* wp; size_t ts, so; };
+struct WFrag { uint4 q[4][3]; };  // the three split terms of the four 16-channel slabs of one tap
+
+// fetch the fragments of packed tap wt (L2): issued a whole layer epilogue ahead of their first use
+template <int NJ = 4>
+__device__ __forceinline__ void kload(WFrag& f, const WS& w, int wt, unsigned lane16) {
+  int opq = 0;
+  asm volatile("" : "+v"(opq));  // (the address arithmetic stays here: see krun)
+  lane16 += (unsigned)opq;
+  const bf16_t* w0 = w.wp + (size_t)wt * w.ts;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      f.q[j][s] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w0 + s * w.so + (size_t)j * JS) + lane16);
+}
 
 // acc += sum_{t < ntaps} sum_{j < 4} W[wt(t)][j] (A operand) x plane pixels at aoff(t), channels 16 j .. (B operand), for the
 // three split terms: six MFMAs per (tap, 16 channels), one memory instruction behind each of them - the LDS reads of the NEXT
 // slab's pixel fragments (double buffer) and the L2 reads of the NEXT TAP's weight fragments into the slots just consumed (24
-// MFMAs ahead: one slab ahead, ~200 cycles, does not cover an L2 hit).  ap: the lane's fragment address in plane 0 at tap
-// offset 0; wp: the wave's weight fragment base; tapf(t, aoff, wt): LDS offset and packed-weight tap of step t.
+// MFMAs ahead: one slab ahead, ~200 cycles, does not cover an L2 hit).  f: the fragments of tap 0 (kload).  ap: the lane's
+// fragment address in plane 0 at tap offset 0; tapf(t, aoff, wt): LDS offset and packed-weight tap of step t.
 template <class F>
-__device__ __forceinline__ void kseg(f32x16& acc, const bf16_t* ap, int pl, const bf16_t* wp, size_t tapstride, size_t split_off,
-                                     unsigned lane16, int ntaps, F tapf) {
+__device__ __forceinline__ void krun(f32x16& acc, WFrag& f, const bf16_t* ap, int pl, const WS& w, unsigned lane16, int ntaps, F tapf) {
   constexpr int NJ = 4;
   // opaque copies: the fragment addresses are formed HERE, per call - left alone hipcc hoists the address arithmetic of all
-  // eighteen call sites out of the image loop and spills it (1.5 KB of scratch per lane)
+  // call sites out of the image loop and spills it (1.5 KB of scratch per lane)
   int opq = 0;
   asm volatile("" : "+v"(opq));
   lane16 += (unsigned)opq;
   ap += opq;
-  uint4 a[2][3], bq[NJ][3];
+  uint4 a[2][3];
   int aoff, wt;
   tapf(0, aoff, wt);
-  {
-    const bf16_t* w0 = wp + (size_t)wt * tapstride;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-        bq[j][s] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w0 + s * split_off + (size_t)j * JS) + lane16);
-  }
 #pragma unroll
   for (int s = 0; s < 3; ++s) a[0][s] = *reinterpret_cast<const uint4*>(ap + s * pl + aoff);
 #pragma unroll 1
   for (int t = 0; t < ntaps; ++t) {
     int aoffn, wtn;
     tapf(t + 1 < ntaps ? t + 1 : t, aoffn, wtn);  // (clamped: the last prefetch re-reads valid data, unused)
-    const bf16_t* wnext = wp + (size_t)wtn * tapstride;
+    const bf16_t* wnext = w.wp + (size_t)wtn * w.ts;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int c = j & 1, nx = c ^ 1;
       const bf16_t* an = ap + ((j + 1 == NJ) ? aoffn : aoff + (j + 1) * 16);
       const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, a[c][0]), a2 = __builtin_bit_cast(bf16x8_t, a[c][1]), a3 = __builtin_bit_cast(bf16x8_t, a[c][2]);
-      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, bq[j][0]), b2 = __builtin_bit_cast(bf16x8_t, bq[j][1]), b3 = __builtin_bit_cast(bf16x8_t, bq[j][2]);
+      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, f.q[j][0]), b2 = __builtin_bit_cast(bf16x8_t, f.q[j][1]), b3 = __builtin_bit_cast(bf16x8_t, f.q[j][2]);
       __builtin_amdgcn_sched_barrier(0);
       // pixel terms a (B operand), weight terms b (A operand); products a1b3, a2b2, a1b2, a3b1, a2b1, a1b1 (small terms first)
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1, acc, 0, 0, 0);
+#ifndef DM_LR_NOA
       a[nx][0] = *reinterpret_cast<const uint4*>(an);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2, acc, 0, 0, 0);
+#ifndef DM_LR_NOA
       a[nx][1] = *reinterpret_cast<const uint4*>(an + pl);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1, acc, 0, 0, 0);
+#ifndef DM_LR_NOA
       a[nx][2] = *reinterpret_cast<const uint4*>(an + 2 * pl);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3, acc, 0, 0, 0);
-      bq[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * split_off + (size_t)j * JS) + lane16);
+#ifndef DM_LR_NOB
+      f.q[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * w.so + (size_t)j * JS) + lane16);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2, acc, 0, 0, 0);
-      bq[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + split_off + (size_t)j * JS) + lane16);
+#ifndef DM_LR_NOB
+      f.q[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + w.so + (size_t)j * JS) + lane16);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc, 0, 0, 0);
-      bq[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+#ifndef DM_LR_NOB
+      f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     aoff = aoffn; wt = wtn;
+  }
+}
+
+// krun for TWO 32-pixel blocks per wave (all 64 pixels of an 8x8 layer): each weight fragment is fetched once per workgroup
+// instead of once per pixel half - the 8x8 layers' weight traffic (442 KB per layer and image with 2 x 2 waves) is what an
+// L2 -> CU path of ~64 B/clk cannot deliver beside the MFMAs - and used for 12 MFMAs.  NJ = 2: the wave covers HALF of K
+// (channel slabs 2kh, 2kh+1 of every tap; caller offsets ap and w.wp) and the partial sums meet through LDS (kx_exchange);
+// NJ = 4: all of K.  ap0/ap1: the lane's fragment addresses for the two blocks.
+template <int NJ, class F>
+__device__ __forceinline__ void krun2(f32x16& acc0, f32x16& acc1, WFrag& f, const bf16_t* ap0, const bf16_t* ap1, int pl, const WS& w,
+                                      unsigned lane16, int ntaps, F tapf) {
+  static_assert(NJ == 2 || NJ == 4, "even slab count: the double buffer alternates per slab");
+  int opq = 0;
+  asm volatile("" : "+v"(opq));
+  lane16 += (unsigned)opq;
+  ap0 += opq;
+  ap1 += opq;
+  uint4 a[2][2][3];  // [buffer][block][split plane]
+  int aoff, wt;
+  tapf(0, aoff, wt);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    a[0][0][s] = *reinterpret_cast<const uint4*>(ap0 + s * pl + aoff);
+    a[0][1][s] = *reinterpret_cast<const uint4*>(ap1 + s * pl + aoff);
+  }
+#pragma unroll 1
+  for (int t = 0; t < ntaps; ++t) {
+    int aoffn, wtn;
+    tapf(t + 1 < ntaps ? t + 1 : t, aoffn, wtn);
+    const bf16_t* wnext = w.wp + (size_t)wtn * w.ts;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int c = j & 1, nx = c ^ 1;
+      const int no = (j + 1 == NJ) ? aoffn : aoff + (j + 1) * 16;
+      const bf16_t* an0 = ap0 + no;
+      const bf16_t* an1 = ap1 + no;
+      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, f.q[j][0]), b2 = __builtin_bit_cast(bf16x8_t, f.q[j][1]), b3 = __builtin_bit_cast(bf16x8_t, f.q[j][2]);
+      const bf16x8_t p1 = __builtin_bit_cast(bf16x8_t, a[c][0][0]), p2 = __builtin_bit_cast(bf16x8_t, a[c][0][1]), p3 = __builtin_bit_cast(bf16x8_t, a[c][0][2]);
+      const bf16x8_t q1 = __builtin_bit_cast(bf16x8_t, a[c][1][0]), q2 = __builtin_bit_cast(bf16x8_t, a[c][1][1]), q3 = __builtin_bit_cast(bf16x8_t, a[c][1][2]);
+      __builtin_amdgcn_sched_barrier(0);
+      // products a1b3, a2b2, a1b2, a3b1, a2b1, a1b1 (small terms first), block 0 then block 1; one memory instruction behind
+      // each of the first nine MFMAs: the next slab's six pixel fragments (LDS), then the next tap's weight fragments (L2)
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, p1, acc0, 0, 0, 0);
+      a[nx][0][0] = *reinterpret_cast<const uint4*>(an0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, q1, acc1, 0, 0, 0);
+      a[nx][1][0] = *reinterpret_cast<const uint4*>(an1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, p2, acc0, 0, 0, 0);
+      a[nx][0][1] = *reinterpret_cast<const uint4*>(an0 + pl);
+      __builtin_amdgcn_sched_barrier(0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, q2, acc1, 0, 0, 0);
+      a[nx][1][1] = *reinterpret_cast<const uint4*>(an1 + pl);
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, p1, acc0, 0, 0, 0);
+      a[nx][0][2] = *reinterpret_cast<const uint4*>(an0 + 2 * pl);
+      __builtin_amdgcn_sched_barrier(0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, q1, acc1, 0, 0, 0);
+      a[nx][1][2] = *reinterpret_cast<const uint4*>(an1 + 2 * pl);
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, p3, acc0, 0, 0, 0);
+      f.q[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * w.so + (size_t)j * JS) + lane16);
+      __builtin_amdgcn_sched_barrier(0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, q3, acc1, 0, 0, 0);
+      f.q[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + w.so + (size_t)j * JS) + lane16);
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, p2, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, q2, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, p1, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, q1, acc1, 0, 0, 0);
+      f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    aoff = aoffn; wt = wtn;
+  }
+}
+
+// The two K halves of an 8x8 layer meet: wave (kh, nb) keeps the pixel half kh of its output block and adds the partner's
+// (kh ^ 1, nb) partial sum of it, sent through X ([4 waves][4][64 lanes] float4 = 16 KiB).  One barrier - which also tells
+// every wave that the K loops are over (the input planes may be rewritten).  Result in acc0.
+__device__ __forceinline__ void kx_exchange(f32x16& acc0, const f32x16& acc1, int kh, int wave, int lane, float* X) {
+  float4* X4 = reinterpret_cast<float4*>(X);
+  if (kh) {  // (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) X4[(wave * 4 + q) * 64 + lane] = make_float4(acc0[4 * q], acc0[4 * q + 1], acc0[4 * q + 2], acc0[4 * q + 3]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) X4[(wave * 4 + q) * 64 + lane] = make_float4(acc1[4 * q], acc1[4 * q + 1], acc1[4 * q + 2], acc1[4 * q + 3]);
+  }
+  __syncthreads();
+  const int pw = wave ^ 2;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = X4[(pw * 4 + q) * 64 + lane];
+    acc0[4 * q] += v.x; acc0[4 * q + 1] += v.y; acc0[4 * q + 2] += v.z; acc0[4 * q + 3] += v.w;
   }
 }
 
@@ -133,7 +258,7 @@ __device__ __forceinline__ void zero_acc(f32x16& acc) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 }
 
-// lane l of wave (., wn) holds channels wn*32 + 8k + 4(l>>5) + e in acc[4k + e]
+// lane l of wave (., wn) holds channels wn*32 + 8k + 4(l>>5) + e in acc[4k + e]; bias: this layer's row of the LDS table
 __device__ __forceinline__ void add_bias(f32x16& acc, const float* bias, int cb) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -152,18 +277,11 @@ __device__ __forceinline__ float wave_sum(float v) {
 // GroupNorm(8) + SiLU (+ time embedding) of a layer's output IN the accumulator registers.  Statistics: whole-image (mean, M2)
 // per group, two passes over the registers; `valid`: this lane holds a pixel; NW: waves that share a group's pixels (2 at
 // 8x8: the pixel halves meet through `red` and two barriers; 1 at 4x4: lanes only, no barrier).  Every wave of the
-// workgroup must call the NW = 2 form.  inv_cnt = 1 / (pixels x 8 channels).
+// workgroup must call the NW = 2 form.  inv_cnt = 1 / (pixels x 8 channels).  gamma, beta, temb: rows of the LDS tables
+// (temb null: no time embedding).
 template <int NW>
 __device__ __forceinline__ void gn_silu_regs(f32x16& acc, bool valid, float inv_cnt, const float* gamma, const float* beta,
                                              const float* temb, int cb, float* red, int wave, int wn) {
-  // affine parameters and time embedding of this lane's 16 channels: issued first, they arrive while the sums are taken
-  float4 gm[4], bt[4], te[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    gm[k] = *reinterpret_cast<const float4*>(gamma + cb + 8 * k);
-    bt[k] = *reinterpret_cast<const float4*>(beta + cb + 8 * k);
-    te[k] = temb ? *reinterpret_cast<const float4*>(temb + cb + 8 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
   float mu[4], m2[4];
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -196,12 +314,15 @@ __device__ __forceinline__ void gn_silu_regs(f32x16& acc, bool valid, float inv_
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + cb + 8 * k);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + cb + 8 * k);
+    const float4 te = temb ? *reinterpret_cast<const float4*>(temb + cb + 8 * k) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float rstd = rsqrtf(m2[k] * inv_cnt + DM_GN_EPS);
-    const float4 sc = make_float4(rstd * gm[k].x, rstd * gm[k].y, rstd * gm[k].z, rstd * gm[k].w);
-    const float4 sh = make_float4(bt[k].x - mu[k] * sc.x, bt[k].y - mu[k] * sc.y, bt[k].z - mu[k] * sc.z, bt[k].w - mu[k] * sc.w);
+    const float4 sc = make_float4(rstd * gm.x, rstd * gm.y, rstd * gm.z, rstd * gm.w);
+    const float4 sh = make_float4(bt.x - mu[k] * sc.x, bt.y - mu[k] * sc.y, bt.z - mu[k] * sc.z, bt.w - mu[k] * sc.w);
     const float4 w = make_float4(fmaf(acc[4 * k], sc.x, sh.x), fmaf(acc[4 * k + 1], sc.y, sh.y), fmaf(acc[4 * k + 2], sc.z, sh.z),
                                  fmaf(acc[4 * k + 3], sc.w, sh.w));
-    const float4 o = dm_silu_add4(w, te[k]);
+    const float4 o = dm_silu_add4(w, te);
     acc[4 * k] = o.x; acc[4 * k + 1] = o.y; acc[4 * k + 2] = o.z; acc[4 * k + 3] = o.w;
   }
 }
@@ -218,6 +339,18 @@ __device__ __forceinline__ void put_planes(const f32x16& acc, bf16_t* buf, int p
     *reinterpret_cast<uint2*>(q + 8 * k + pl) = s2;
     *reinterpret_cast<uint2*>(q + 8 * k + 2 * pl) = s3;
   }
+}
+
+// eight fp32 values (two float4) -> three bf16 planes, 16 bytes each, at q
+__device__ __forceinline__ void put_planes8(float4 w0, float4 w1, bf16_t* q, int pl) {
+  uint4 s1, s2, s3;
+  dm_split3(w0.x, w0.y, s1.x, s2.x, s3.x);
+  dm_split3(w0.z, w0.w, s1.y, s2.y, s3.y);
+  dm_split3(w1.x, w1.y, s1.z, s2.z, s3.z);
+  dm_split3(w1.z, w1.w, s1.w, s2.w, s3.w);
+  *reinterpret_cast<uint4*>(q) = s1;
+  *reinterpret_cast<uint4*>(q + pl) = s2;
+  *reinterpret_cast<uint4*>(q + 2 * pl) = s3;
 }
 
 // the lane's 16 values as fp32 at q (+ 8k per run)
@@ -249,17 +382,19 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
   extern __shared__ __attribute__((aligned(16))) float smem[];
   bf16_t* P = reinterpret_cast<bf16_t*>(smem);
   bf16_t* D3p = P + 3 * PL;
-  float* sm = reinterpret_cast<float*>(D3p + 3 * PL4);
+  float* X8 = reinterpret_cast<float*>(D3p);  // 8x8 level: K-split exchange area (D3p is live during the 4x4 level only)
+  float* sm = reinterpret_cast<float*>(reinterpret_cast<char*>(D3p) + X8_BYTES);
   bf16_t* E = P;                    // 4x4-level buffers live in P while the 8x8 level does not need it
   bf16_t* Fb = P + 3 * PL4;
   float* X = reinterpret_cast<float*>(reinterpret_cast<char*>(P) + X_OFF);
-  float* s_scale = sm;              // [64] input stage only
-  float* s_shift = sm + 64;         // [64]
-  float* red = sm + 128;            // [32]
+  float* s_scale = sm + SM_SCALE;   // [64] input stage only
+  float* s_shift = sm + SM_SHIFT;   // [64]
+  float* red = sm + SM_RED;         // [32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
   const int wn_s = __builtin_amdgcn_readfirstlane(wn), wm_s = __builtin_amdgcn_readfirstlane(wm);
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lane16 = (unsigned)lane * 16u;
   const int cb = wn * 32 + 4 * h;   // first channel of the lane's run 0
   const int step = (p.step_ptr ? *p.step_ptr : 0) + p.step_off;
@@ -270,13 +405,49 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
   const size_t TS64 = 4 * JS, TS128 = 8 * JS;  // tap strides for 64 / 128 input channels
   const size_t wofs = (size_t)wn_s * 512;      // this wave's 32 output channels
 
-  zero_ring<6>(D3p, PL4);  // its halo is written here only; the interior is rewritten per image
+  // ---- once per workgroup: every layer's bias and GroupNorm affine parameters -> LDS (wave w takes layers w, w+4, w+8)
+  {
+    const LrLayer* Ls[12] = {&p.d2t, &p.d3c1, &p.d3c2, &p.d3t, &p.b0, &p.b3, &p.u1c1, &p.u1c2, &p.u1t, &p.u2c1, &p.u2c2, &p.u2t};
+    int ni = 0;
+#pragma unroll
+    for (int l = 0; l < 12; ++l) {
+      if ((l & 3) == wave_s) sm[SM_BIAS + l * 64 + lane] = Ls[l]->bias[lane];
+      if (Ls[l]->gamma) {  // (uniform; the normed layers are the same for every launch: d3c1, d3c2, b0, u1c1, u1c2, u2c1, u2c2)
+        if ((l & 3) == wave_s) {
+          sm[SM_GAMMA + ni * 64 + lane] = Ls[l]->gamma[lane];
+          sm[SM_BETA + ni * 64 + lane] = Ls[l]->beta[lane];
+        }
+        ++ni;
+      }
+    }
+  }
+  const float* bias_t = sm + SM_BIAS;
+
+  // weight streams (wave-uniform): {fragment base, tap stride, split stride}
+  // (8x8 layers: the wave pair index wm is the K half kh - channel slabs 2kh, 2kh+1 -, see krun2)
+  const size_t kofs = (size_t)wm_s * 2 * JS;
+  const WS w_d2t = {p.d2t.w + wofs + kofs, TS64, 16 * TS64}, w_d3c1 = {p.d3c1.w + wofs + kofs, TS64, 9 * TS64}, w_d3c2 = {p.d3c2.w + wofs + kofs, TS64, 9 * TS64};
+  const WS w_d3t = {p.d3t.w + wofs, TS64, 16 * TS64}, w_b0 = {p.b0.w + wofs, TS64, 9 * TS64}, w_b3 = {p.b3.w + wofs, TS64, 9 * TS64};
+  const WS w_u1c1 = {p.u1c1.w + wofs + (size_t)wm_s * 4 * JS, TS128, 9 * TS128}, w_u1c2 = {p.u1c2.w + wofs, TS64, 9 * TS64};
+  const WS w_u1t = {p.u1t.w + wofs, TS64, 16 * TS64}, w_u2c1a = {p.u2c1.w + wofs + kofs, TS128, 9 * TS128};
+  const WS w_u2c1b = {p.u2c1.w + wofs + 4 * JS + kofs, TS128, 9 * TS128}, w_u2c2 = {p.u2c2.w + wofs + kofs, TS64, 9 * TS64}, w_u2t = {p.u2t.w + wofs, TS64, 16 * TS64};
+
+  WFrag wf;
+  // taps of the input phase (a, b) of a stride-2 conv: ky = 2ty + 1 - a, kx = 2tx + 1 - b
+  auto wt_phase = [](int pa, int pb, int ty, int tx) { return (2 * ty + 1 - pa) * 4 + 2 * tx + 1 - pb; };
+  if (blockIdx.x < p.B) kload<2>(wf, w_d2t, wt_phase(0, 0, 0, 0), lane16);
+  // the lane's fragment offsets for the two 32-pixel blocks of an 8x8 layer (pixel b*32 + l31), K half kh = wm
+  const int y8a = l31 >> 3, y8b = 4 + (l31 >> 3), x8l = l31 & 7;
+  const int kh_el = wm * 32;  // first channel of the wave's K half
 
   for (int n = blockIdx.x; n < p.B; n += gridDim.x) {
-    const float* hd = p.heads + (size_t)step * p.heads_step_stride + (size_t)n * p.heads_img_stride;
-    auto temb_of = [&](const LrLayer& L) { return L.temb_k >= 0 ? hd + L.temb_k * 64 : (const float*)nullptr; };
-    f32x16 acc;
+    f32x16 acc, acc1;
     LR_STAMP(0);
+    // time-embedding rows of this image's three normed conv1 layers (blocks down3, up1, up2) -> LDS (first read in phase B)
+    if (wave_s < 3) {
+      const float* hd = p.heads + (size_t)step * p.heads_step_stride + (size_t)n * p.heads_img_stride;
+      sm[SM_TEMB + wave_s * 64 + lane] = hd[(2 + wave_s) * 64 + lane];
+    }
 
     // ================= A: down2.transform, Conv2d 4x4 s2 p1, 16x16 -> 8x8 (model.py:46,64) =================
     // input = SiLU(GroupNorm(t2)) (down2.bnorm2; no time embedding after the second norm), staged one input phase (row parity a,
@@ -298,77 +469,85 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       s_shift[c] = p.b2[c] - mean * sc;
     }
     zero_acc(acc);
+    zero_acc(acc1);
     const float* src = p.t2 + (size_t)n * 16 * 16 * 64;
-    for (int ph = 0; ph < 4; ++ph) {
+    float4 v0[3], v1[3];
+    unsigned inbm = 0;
+    // the three (pixel, channel octet) items of this thread for phase ph: loads from clamped addresses, padding by a mask
+    auto fetch = [&](int ph) {
       const int pa = ph >> 1, pb = ph & 1;
-      __syncthreads();  // tables ready / the previous phase's (previous image's) reads of P are done
-      float4 v0[3], v1[3];
-      bool inb[3];
+      inbm = 0;
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int idx = tid + 256 * u;
         const int pix = min(idx >> 3, 80), c8 = idx & 7;
         const int Y = pix / 9, Xc = pix - Y * 9;
         const int iy = 2 * Y - pa, ix = 2 * Xc - pb;
-        inb[u] = (unsigned)iy < 16u && (unsigned)ix < 16u;
+        inbm |= ((unsigned)iy < 16u && (unsigned)ix < 16u) ? (1u << u) : 0u;
         const float* q = src + ((min(max(iy, 0), 15) * 16 + min(max(ix, 0), 15)) * 64 + c8 * 8);
         v0[u] = *reinterpret_cast<const float4*>(q);
         v1[u] = *reinterpret_cast<const float4*>(q + 4);
       }
+    };
+    fetch(0);
+    for (int ph = 0; ph < 4; ++ph) {
+      const int pa = ph >> 1, pb = ph & 1;
+      __syncthreads();  // tables ready / the previous phase's (previous image's) reads of P are done
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int idx = tid + 256 * u;
         if (idx < 81 * 8) {
           const int pix = idx >> 3, c8 = idx & 7;
           float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
-          if (inb[u]) {
+          if ((inbm >> u) & 1) {
             const float4 sc0 = *reinterpret_cast<const float4*>(s_scale + c8 * 8), sc1 = *reinterpret_cast<const float4*>(s_scale + c8 * 8 + 4);
             const float4 sh0 = *reinterpret_cast<const float4*>(s_shift + c8 * 8), sh1 = *reinterpret_cast<const float4*>(s_shift + c8 * 8 + 4);
             w0 = dm_silu_add4(make_float4(fmaf(v0[u].x, sc0.x, sh0.x), fmaf(v0[u].y, sc0.y, sh0.y), fmaf(v0[u].z, sc0.z, sh0.z), fmaf(v0[u].w, sc0.w, sh0.w)), make_float4(0.f, 0.f, 0.f, 0.f));
             w1 = dm_silu_add4(make_float4(fmaf(v1[u].x, sc1.x, sh1.x), fmaf(v1[u].y, sc1.y, sh1.y), fmaf(v1[u].z, sc1.z, sh1.z), fmaf(v1[u].w, sc1.w, sh1.w)), make_float4(0.f, 0.f, 0.f, 0.f));
           }
-          uint4 s1, s2, s3;
-          dm_split3(w0.x, w0.y, s1.x, s2.x, s3.x);
-          dm_split3(w0.z, w0.w, s1.y, s2.y, s3.y);
-          dm_split3(w1.x, w1.y, s1.z, s2.z, s3.z);
-          dm_split3(w1.z, w1.w, s1.w, s2.w, s3.w);
-          bf16_t* q = P + pix * RSB + c8 * 8;
-          *reinterpret_cast<uint4*>(q) = s1;
-          *reinterpret_cast<uint4*>(q + PL) = s2;
-          *reinterpret_cast<uint4*>(q + 2 * PL) = s3;
+          put_planes8(w0, w1, P + pix * RSB + c8 * 8, PL);
         }
       }
+      if (ph < 3) fetch(ph + 1);  // the next phase's pixels travel while this phase's MFMAs run
       __syncthreads();
-      kseg(acc, P + (y8 * 9 + x8) * RSB + 8 * h, PL, p.d2t.w + wofs, TS64, 16 * TS64, lane16, 4,
-              [&](int t, int& ao, int& wt) { ao = ((t >> 1) * 9 + (t & 1)) * RSB; wt = (2 * (t >> 1) + 1 - pa) * 4 + 2 * (t & 1) + 1 - pb; });
+      krun2<2>(acc, acc1, wf, P + (y8a * 9 + x8l) * RSB + 8 * h + kh_el, P + (y8b * 9 + x8l) * RSB + 8 * h + kh_el, PL, w_d2t, lane16, 4,
+               [&](int t, int& ao, int& wt) { ao = ((t >> 1) * 9 + (t & 1)) * RSB; wt = wt_phase(pa, pb, t >> 1, t & 1); });
+      if (ph < 3) kload<2>(wf, w_d2t, wt_phase((ph + 1) >> 1, (ph + 1) & 1, 0, 0), lane16);
     }
-    add_bias(acc, p.d2t.bias, cb);
-    {  // down2's output, raw: to global (skip input of up2.conv1, read back by this workgroup) and, as planes, the input of down3.conv1
-      float* q = p.d2 + ((size_t)n * 64 + m8) * 64 + cb;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(q + 8 * k) = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
-    }
-    __syncthreads();  // every wave is done reading the phase planes
+    kload<2>(wf, w_d3c1, 0, lane16);
+    kx_exchange(acc, acc1, wm, wave, lane, X8);  // (its barrier: every wave is done reading the phase planes)
+    add_bias(acc, bias_t + 0 * 64, cb);
+    put_f32(acc, p.d2 + ((size_t)n * 64 + m8) * 64 + cb);  // down2's output, raw: skip input of up2.conv1, read back by this workgroup
     zero_ring<10>(P, PL);
-    put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
+    put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);  // ... and, as planes, the input of down3.conv1
 
     LR_STAMP(1);
     // ================= B, C: down3.conv1, down3.conv2, Conv2d 3x3 p1 at 8x8 (model.py:54-62) =================
-    const bf16_t* a8 = P + (y8 * 10 + x8) * RSB + 8 * h;
+    const bf16_t* a8a = P + (y8a * 10 + x8l) * RSB + 8 * h + kh_el;  // blocks 0 / 1 of the 10x10 layout, K half kh
+    const bf16_t* a8b = P + (y8b * 10 + x8l) * RSB + 8 * h + kh_el;
     auto tap3_10 = [&](int t, int& ao, int& wt) { const int ty = t / 3; ao = (ty * 10 + t - 3 * ty) * RSB; wt = t; };
     __syncthreads();
     zero_acc(acc);
-    kseg(acc, a8, PL, p.d3c1.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
-    add_bias(acc, p.d3c1.bias, cb);
-    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.d3c1.gamma, p.d3c1.beta, temb_of(p.d3c1), cb, red, wave, wn);
+    zero_acc(acc1);
+    LR_STAMP(13);
+    krun2<2>(acc, acc1, wf, a8a, a8b, PL, w_d3c1, lane16, 9, tap3_10);
+    LR_STAMP(14);
+    kload<2>(wf, w_d3c2, 0, lane16);
+    kx_exchange(acc, acc1, wm, wave, lane, X8);
+    add_bias(acc, bias_t + 1 * 64, cb);
+    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 0 * 64, sm + SM_BETA + 0 * 64, sm + SM_TEMB + 0 * 64, cb, red, wave, wn);
+    LR_STAMP(15);
     // (the two barriers inside: every wave is past its K loop, P may be rewritten; the halo ring stays zero)
     put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
     LR_STAMP(2);
     __syncthreads();
     zero_acc(acc);
-    kseg(acc, a8, PL, p.d3c2.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
-    add_bias(acc, p.d3c2.bias, cb);
-    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.d3c2.gamma, p.d3c2.beta, temb_of(p.d3c2), cb, red, wave, wn);
+    zero_acc(acc1);
+    krun2<2>(acc, acc1, wf, a8a, a8b, PL, w_d3c2, lane16, 9, tap3_10);
+    kload(wf, w_d3t, wt_phase(wm_s, 0, 0, 0), lane16);
+    kx_exchange(acc, acc1, wm, wave, lane, X8);
+    add_bias(acc, bias_t + 2 * 64, cb);
+    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 1 * 64, sm + SM_BETA + 1 * 64, nullptr, cb, red, wave, wn);
     // output in the four-phase layout of the stride-2 conv: input pixel (y, x) = (2Y - a, 2X - b) -> plane (a, b) pixel (Y, X) of 5x5
     {
       const int pa = y8 & 1, pb = x8 & 1;
@@ -385,14 +564,12 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     // ================= D: down3.transform, Conv2d 4x4 s2 p1, 8x8 -> 4x4: K split by input phase over the wave pairs =================
     __syncthreads();
     zero_acc(acc);
-    {
-      const bf16_t* ad = P + (y4 * 5 + x4) * RSB + 8 * h;
-      kseg(acc, ad, PL, p.d3t.w + wofs, TS64, 16 * TS64, lane16, 8, [&](int t, int& ao, int& wt) {
-        const int ph = 2 * wm_s + (t >> 2), pa = ph >> 1, pb = ph & 1, ty = (t >> 1) & 1, tx = t & 1;
-        ao = (ph * 25 + ty * 5 + tx) * RSB;
-        wt = (2 * ty + 1 - pa) * 4 + 2 * tx + 1 - pb;
-      });
-    }
+    krun(acc, wf, P + (y4 * 5 + x4) * RSB + 8 * h, PL, w_d3t, lane16, 8, [&](int t, int& ao, int& wt) {
+      const int ph = 2 * wm_s + (t >> 2), ty = (t >> 1) & 1, tx = t & 1;
+      ao = (ph * 25 + ty * 5 + tx) * RSB;
+      wt = wt_phase(ph >> 1, ph & 1, ty, tx);
+    });
+    kload(wf, w_b0, 5 * wm_s, lane16);
     __syncthreads();  // P is dead: the 4x4-level buffers E, F and the exchange area take its place
     if (wm) {
 #pragma unroll
@@ -400,12 +577,13 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     }
     zero_ring<6>(E, PL4);
     zero_ring<6>(Fb, PL4);
+    zero_ring<6>(D3p, PL4);  // (the buffer served as the 8x8 level's exchange area)
     __syncthreads();
     const int pix6 = (y4 + 1) * 6 + x4 + 1;
     if (!wm) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += X[(wn * 16 + r) * 64 + lane];
-      add_bias(acc, p.d3t.bias, cb);
+      add_bias(acc, bias_t + 3 * 64, cb);
       if (v4) put_planes(acc, D3p, PL4, pix6, cb);  // down3's output, raw: input of bottleneck.0 and skip input of up1.conv1
       if (p.taps && v4) put_f32(acc, p.taps + (size_t)n * 6144 + m4 * 64 + cb);
     }
@@ -414,13 +592,16 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     // ================= E..H: bottleneck.0, bottleneck.3, up1.conv1, up1.conv2, Conv2d 3x3 p1 at 4x4 =================
     // 16 pixels: the pixel-half index wm splits K (taps 0..4 | 5..8; up1.conv1: one input per half)
     auto tap3_6 = [&](int t, int& ao, int& wt) { const int ty = t / 3; ao = (ty * 6 + t - 3 * ty) * RSB; wt = t; };
-    auto conv4 = [&](const bf16_t* in0, const bf16_t* in1, const LrLayer& L, bf16_t* out, int tap_off) {
+    // in1 != null: K = [in0, in1] channels, one input per wave pair.  After the K loop the next layer's first weight
+    // fragments are requested (wsn, wtn0), then the partial sums meet and the wm = 0 pair finishes the layer.
+    auto conv4 = [&](const bf16_t* in0, const bf16_t* in1, const WS& ws, int li, int ni, const float* temb, bf16_t* out, int tap_off,
+                     const WS& wsn, int wtn0) {
       __syncthreads();  // the input planes are complete; the exchange area is free
       zero_acc(acc);
       const int a4 = (y4 * 6 + x4) * RSB + 8 * h;
-      if (in1) kseg(acc, (wm_s ? in1 : in0) + a4, PL4, L.w + wofs + (size_t)wm_s * 4 * JS, TS128, 9 * TS128, lane16, 9, tap3_6);
-      else kseg(acc, in0 + a4, PL4, L.w + wofs, TS64, 9 * TS64, lane16, wm_s ? 4 : 5,
-                [&](int t, int& ao, int& wt) { tap3_6(t + 5 * wm_s, ao, wt); });
+      if (in1) krun(acc, wf, (wm_s ? in1 : in0) + a4, PL4, ws, lane16, 9, tap3_6);
+      else krun(acc, wf, in0 + a4, PL4, ws, lane16, wm_s ? 4 : 5, [&](int t, int& ao, int& wt) { tap3_6(t + 5 * wm_s, ao, wt); });
+      kload(wf, wsn, wtn0, lane16);
       if (wm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) X[(wn * 16 + r) * 64 + lane] = acc[r];
@@ -429,37 +610,36 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       if (!wm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += X[(wn * 16 + r) * 64 + lane];
-        add_bias(acc, L.bias, cb);
-        if (L.gamma) gn_silu_regs<1>(acc, v4, 1.0f / 128.0f, L.gamma, L.beta, temb_of(L), cb, red, wave, wn);
+        add_bias(acc, bias_t + li * 64, cb);
+        if (ni >= 0) gn_silu_regs<1>(acc, v4, 1.0f / 128.0f, sm + SM_GAMMA + ni * 64, sm + SM_BETA + ni * 64, temb, cb, red, wave, wn);
         if (v4) put_planes(acc, out, PL4, pix6, cb);
         if (tap_off >= 0 && p.taps && v4) put_f32(acc, p.taps + (size_t)n * 6144 + tap_off + m4 * 64 + cb);
       }
     };
-    conv4(D3p, nullptr, p.b0, E, -1);
+    conv4(D3p, nullptr, w_b0, 4, 2, nullptr, E, -1, w_b3, 5 * wm_s);
     LR_STAMP(5);
-    conv4(E, nullptr, p.b3, Fb, 1024);
+    conv4(E, nullptr, w_b3, 5, -1, nullptr, Fb, 1024, w_u1c1, 0);
     LR_STAMP(6);
-    conv4(Fb, D3p, p.u1c1, E, -1);
+    conv4(Fb, D3p, w_u1c1, 6, 3, sm + SM_TEMB + 1 * 64, E, -1, w_u1c2, 5 * wm_s);
     LR_STAMP(7);
-    conv4(E, nullptr, p.u1c2, Fb, -1);
+    conv4(E, nullptr, w_u1c2, 7, 4, nullptr, Fb, -1, w_u1t, 2 * wm_s * 4);
     LR_STAMP(8);
 
     // ================= I: up1.transform, ConvTranspose2d 4x4 s2 p1, 4x4 -> 8x8: output parities 2wm, 2wm+1 per wave pair =================
     // out[2y+py][2x+px] = sum over ty, tx in {0,1} of in[y-1+py+ty][x-1+px+tx] w[3-py-2ty][3-px-2tx] (packed per parity)
     __syncthreads();
-    f32x16 acc1;
     zero_acc(acc);
     zero_acc(acc1);
     {
       const bf16_t* au = Fb + (y4 * 6 + x4) * RSB + 8 * h;
       const int par0 = 2 * wm_s;
-      kseg(acc, au, PL4, p.u1t.w + wofs, TS64, 16 * TS64, lane16, 4,
-              [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + (t & 1)) * RSB; wt = par0 * 4 + t; });
-      kseg(acc1, au, PL4, p.u1t.w + wofs, TS64, 16 * TS64, lane16, 4,
-              [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + 1 + (t & 1)) * RSB; wt = (par0 + 1) * 4 + t; });
+      krun(acc, wf, au, PL4, w_u1t, lane16, 4, [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + (t & 1)) * RSB; wt = par0 * 4 + t; });
+      kload(wf, w_u1t, (par0 + 1) * 4, lane16);
+      krun(acc1, wf, au, PL4, w_u1t, lane16, 4, [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + 1 + (t & 1)) * RSB; wt = (par0 + 1) * 4 + t; });
     }
-    add_bias(acc, p.u1t.bias, cb);
-    add_bias(acc1, p.u1t.bias, cb);
+    kload<2>(wf, w_u2c1a, 0, lane16);
+    add_bias(acc, bias_t + 8 * 64, cb);
+    add_bias(acc1, bias_t + 8 * 64, cb);
     if (p.taps && v4) {
       put_f32(acc, p.taps + (size_t)n * 6144 + 2048 + ((2 * y4 + wm) * 8 + 2 * x4) * 64 + cb);
       put_f32(acc1, p.taps + (size_t)n * 6144 + 2048 + ((2 * y4 + wm) * 8 + 2 * x4 + 1) * 64 + cb);
@@ -475,6 +655,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     // ================= J, K: up2.conv1 over cat[up1, down2] (model.py:147), up2.conv2, Conv2d 3x3 p1 at 8x8 =================
     __syncthreads();
     zero_acc(acc);
+    zero_acc(acc1);
     float4 d2v[2][2];  // down2's output comes back from global memory while the first half of K runs
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -483,46 +664,52 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       d2v[u][0] = *reinterpret_cast<const float4*>(q);
       d2v[u][1] = *reinterpret_cast<const float4*>(q + 4);
     }
-    kseg(acc, a8, PL, p.u2c1.w + wofs, TS128, 9 * TS128, lane16, 9, tap3_10);
+    krun2<2>(acc, acc1, wf, a8a, a8b, PL, w_u2c1a, lane16, 9, tap3_10);
+    kload<2>(wf, w_u2c1b, 0, lane16);
     __syncthreads();  // the up1 planes are consumed
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int idx = tid + 256 * u, pix = idx >> 3, c8 = idx & 7;
-      uint4 s1, s2, s3;
-      dm_split3(d2v[u][0].x, d2v[u][0].y, s1.x, s2.x, s3.x);
-      dm_split3(d2v[u][0].z, d2v[u][0].w, s1.y, s2.y, s3.y);
-      dm_split3(d2v[u][1].x, d2v[u][1].y, s1.z, s2.z, s3.z);
-      dm_split3(d2v[u][1].z, d2v[u][1].w, s1.w, s2.w, s3.w);
-      bf16_t* q = P + (((pix >> 3) + 1) * 10 + (pix & 7) + 1) * RSB + c8 * 8;
-      *reinterpret_cast<uint4*>(q) = s1;
-      *reinterpret_cast<uint4*>(q + PL) = s2;
-      *reinterpret_cast<uint4*>(q + 2 * PL) = s3;
+      put_planes8(d2v[u][0], d2v[u][1], P + (((pix >> 3) + 1) * 10 + (pix & 7) + 1) * RSB + c8 * 8, PL);
     }
     __syncthreads();
-    kseg(acc, a8, PL, p.u2c1.w + wofs + 4 * JS, TS128, 9 * TS128, lane16, 9, tap3_10);
-    add_bias(acc, p.u2c1.bias, cb);
-    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.u2c1.gamma, p.u2c1.beta, temb_of(p.u2c1), cb, red, wave, wn);
+    krun2<2>(acc, acc1, wf, a8a, a8b, PL, w_u2c1b, lane16, 9, tap3_10);
+    kload<2>(wf, w_u2c2, 0, lane16);
+    kx_exchange(acc, acc1, wm, wave, lane, X8);
+    add_bias(acc, bias_t + 9 * 64, cb);
+    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 5 * 64, sm + SM_BETA + 5 * 64, sm + SM_TEMB + 2 * 64, cb, red, wave, wn);
     put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
     LR_STAMP(10);
     __syncthreads();
     zero_acc(acc);
-    kseg(acc, a8, PL, p.u2c2.w + wofs, TS64, 9 * TS64, lane16, 9, tap3_10);
-    add_bias(acc, p.u2c2.bias, cb);
-    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, p.u2c2.gamma, p.u2c2.beta, temb_of(p.u2c2), cb, red, wave, wn);
+    zero_acc(acc1);
+    krun2<2>(acc, acc1, wf, a8a, a8b, PL, w_u2c2, lane16, 9, tap3_10);
+    kload(wf, w_u2t, 2 * wm_s * 4, lane16);
+    kx_exchange(acc, acc1, wm, wave, lane, X8);
+    add_bias(acc, bias_t + 10 * 64, cb);
+    gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 6 * 64, sm + SM_BETA + 6 * 64, nullptr, cb, red, wave, wn);
     put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
 
     LR_STAMP(11);
-    // ================= L: up2.transform, ConvTranspose2d 4x4 s2 p1, 8x8 -> 16x16, four output parities from the planes =================
+    // ================= L: up2.transform, ConvTranspose2d 4x4 s2 p1, 8x8 -> 16x16: output parities 2wm, 2wm+1 per wave pair =================
+    // (all 64 pixels per wave, every weight fragment fetched by ONE wave of the workgroup)
     __syncthreads();
-    for (int par = 0; par < 4; ++par) {
-      const int py = par >> 1, px = par & 1;
-      zero_acc(acc);
-      kseg(acc, a8, PL, p.u2t.w + wofs, TS64, 16 * TS64, lane16, 4,
-              [&](int t, int& ao, int& wt) { ao = ((py + (t >> 1)) * 10 + px + (t & 1)) * RSB; wt = par * 4 + t; });
-      add_bias(acc, p.u2t.bias, cb);
-      float* q = p.u2 + (((size_t)n * 16 + 2 * y8 + py) * 16 + 2 * x8 + px) * 64 + cb;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) *reinterpret_cast<float4*>(q + 8 * k) = make_float4(acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]);
+    {
+      const bf16_t* u8a = P + (y8a * 10 + x8l) * RSB + 8 * h;
+      const bf16_t* u8b = P + (y8b * 10 + x8l) * RSB + 8 * h;
+      for (int pp = 0; pp < 2; ++pp) {
+        const int par = 2 * wm_s + pp, py = wm_s, px = pp;
+        zero_acc(acc);
+        zero_acc(acc1);
+        krun2<4>(acc, acc1, wf, u8a, u8b, PL, w_u2t, lane16, 4,
+                 [&](int t, int& ao, int& wt) { ao = ((py + (t >> 1)) * 10 + px + (t & 1)) * RSB; wt = par * 4 + t; });
+        if (pp == 0) kload(wf, w_u2t, (par + 1) * 4, lane16);
+        else if (n + (int)gridDim.x < p.B) kload<2>(wf, w_d2t, wt_phase(0, 0, 0, 0), lane16);  // the next image's first fragments
+        add_bias(acc, bias_t + 11 * 64, cb);
+        add_bias(acc1, bias_t + 11 * 64, cb);
+        put_f32(acc, p.u2 + (((size_t)n * 16 + 2 * y8a + py) * 16 + 2 * x8l + px) * 64 + cb);
+        put_f32(acc1, p.u2 + (((size_t)n * 16 + 2 * y8b + py) * 16 + 2 * x8l + px) * 64 + cb);
+      }
     }
     LR_STAMP(12);
   }

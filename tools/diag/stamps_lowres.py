@@ -21,7 +21,10 @@ for B in [int(a) for a in sys.argv[1:]] or [64, 1024]:
     m(x, t); torch.cuda.synchronize()
     L.dm_debug_set_stamps(None)
     a = st[1 << 20:].cpu().numpy().reshape(-1, 32)
-    a = a[a[:, 0] != 0][:, :13]
+    a = a[a[:, 0] != 0]
+    b = a[:, 13:16]
+    print(f"   phase B split: pre-K {np.median(b[:,0]-a[:,1]):.0f}  K loop {np.median(b[:,1]-b[:,0]):.0f}  bias+GN+SiLU {np.median(b[:,2]-b[:,1]):.0f}  planes {np.median(a[:,2]-b[:,2]):.0f}")
+    a = a[:, :13]
     dlt = np.diff(a, axis=1)
     print(f"B={B}: {len(a)} workgroups; last image: median {np.median(a[:,12]-a[:,0]):.0f} cycles")
     for i, nm in enumerate(NAMES):
