@@ -50,8 +50,21 @@ K_NAMES = ["init_conv", "conv3x3_mfma_t128", "conv3x3_mfma_t64", "conv4x4s2_mfma
 NK = len(K_NAMES)  # DM_K_COUNT
 K_WINO = 10
 MFMA_CLASSES = (1, 2, 3, 4, 5, 9, 10, 11, 12, 13)
-X6_CLASSES = (11, 12, 13)  # fp32 convolutions on the bf16 pipe: six bf16 MFMAs per fp32 product (three-way split operands)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_traffic.json")  # PMC passes of this round's build (profiles/README.md)
+MFMA_CLASSES = MFMA_CLASSES + (14,)
+X6_CLASSES = (11, 12, 13, 16)  # fp32 convolutions on the bf16 pipe: six bf16 MFMAs per fp32 product (three-way split operands)
+# PMC / rocprofv3 summaries of THIS build (profiles/README.md): each file carries the key of the library it was measured on
+# (`build_key`, __graft_entry__.build_key()); a figure whose key differs from the loaded library's is reported as null
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_traffic.json")
+ROCPROF_FILE = os.path.join(ROOT, "profiles", "r3_rocprof_summary.json")
+
+
+def keyed_profile(path):
+    """A committed profile summary, or None when it was measured on another build of the library."""
+    from diffusion_model_amd import _lib
+    if not os.path.exists(path):
+        return None
+    j = json.load(open(path))
+    return j if j.get("build_key") == _lib.lib().dm_build_key().decode() else None
 
 
 def flop_per_image_step(C_, S, cin, cout):
@@ -143,8 +156,23 @@ def run_configs(d, O, dev, sd32):
         for i in range(ns):
             t = torch.tensor(i)
             xr = O.sampler_step(osch, O.unet_forward(sd32, xr, t), t, xr, 1.0, nz[i, :k])
+    # the public entry point, AncestralSampler.__call__ (sampler.py:45-76): x_T and ALL per-step noise drawn from torch's CPU
+    # generator inside the timed region - chunk by chunk in the library's chunk callback, so the draw of chunk k+1 overlaps the
+    # GPU's work on chunk k - plus the H2D copies.  torch.randn itself (the reference pays it too) bounds this from above.
+    torch.manual_seed(11)
+    dt_call, _ = timed_passes(lambda: smp(m32, (B, 1, 32, 32), progress_bar=False), 2)
+    t0 = time.perf_counter()
+    torch.randn((n, B, 1, 32, 32))
+    rng_s = time.perf_counter() - t0
     res["cfg1_ancestral1000_b64_eta1_fp32"] = {
         "images_per_s": B / dt, "ms_per_pass": 1e3 * dt, "batch": B, "steps": n, "noise": "host tensor, staged per 50-step graph chunk",
+        "end_to_end_call": {"images_per_s": B / dt_call, "ms_per_pass": 1e3 * dt_call,
+                            "includes": "AncestralSampler.__call__: x_T draw, the 1000 per-step noise draws (torch CPU generator, one 50-step chunk at a "
+                                        "time into pinned buffers while the GPU runs the previous chunk), H2D, sampling",
+                            "host_rng_ms_per_pass": 1e3 * rng_s, "host_rng_ceiling_images_per_s": B / rng_s,
+                            "note": "torch.randn of the n x B x 1024 noise values alone takes host_rng_ms_per_pass on this host (single-threaded "
+                                    "mt19937 + Box-Muller, bit-identical to the reference's draws): no sampler that keeps the reference's noise can "
+                                    "run faster than host_rng_ceiling_images_per_s; `images_per_s` above is the same loop with the noise pre-drawn"},
         "frac_fp32_mfma_peak_whole_path_algorithmic": B / dt * n * FLOP_PER_IMAGE_STEP / 1e12 / PEAK_FP32_MFMA_TFLOPS,
         "dominant": dominant(per),
         "check_max_abs_vs_cpu_oracle": (got - xr).abs().max().item(), "check": f"first {ns} steps, {k} images, |ref|max {xr.abs().max().item():.3g}"}
@@ -397,6 +425,8 @@ def main():
         "achieved_tflops_whole_path_algorithmic": value * n * flop_img_step / 1e12,
         "frac_fp32_mfma_peak_whole_path_algorithmic": value * n * flop_img_step / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
     }
+    from diffusion_model_amd import _lib as _l
+    res["build_key"] = _l.lib().dm_build_key().decode()  # sha256 of the library's sources + flags (profiles/ summaries are keyed by it)
     if rehearse:
         res["rehearsal"] = "CPU plumbing rehearsal (DM_BENCH_REHEARSE_CPU): stand-in sampler, `value` is not a measurement"
         args.no_roofline = args.no_cpu_baseline = args.no_configs = True
@@ -419,9 +449,12 @@ def main():
         counts, ms, fl, by, tot_ms = raw["counts"], raw["ms"], raw["fl"], raw["by"], raw["tot_ms"]
         k = 1 if args.precision == "bf16" else K_WINO  # dominant: conv_bf16_kernel<2,0> / conv_mfma_kernel<2,5,64> (DM_K_WINO)
         ach = fl[k] / (ms[k] * 1e-3) / 1e12
-        traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/README.md)
-        if os.path.exists(TRAFFIC_FILE) and B == 1024 and args.precision == "fp32":
-            traffic = json.load(open(TRAFFIC_FILE)).get("hbm_bytes_per_launch")
+        # HBM bytes per launch from the committed PMC passes and the rocprofv3 class average, both only if measured on THIS build
+        traffic = rocprof_avg = None
+        if B == 1024 and args.precision == "fp32" and args.model == "mnist":
+            tj, rj = keyed_profile(TRAFFIC_FILE), keyed_profile(ROCPROF_FILE)
+            traffic = tj.get("hbm_bytes_per_launch") if tj else None
+            rocprof_avg = rj.get("winograd_class_avg_us") if rj else None
         if args.precision == "bf16":
             # at 16x the MFMA rate the bf16 conv kernel is bound by its activation traffic
             gbps = by[k] / (ms[k] * 1e-3) / 1e9
@@ -441,6 +474,10 @@ def main():
                                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, B=1024)",
                                "algorithmic_bytes_per_launch": by[k] / counts[k],
                                "avg_launch_us": 1e3 * ms[k] / counts[k], "flop_per_launch": fl[k] / counts[k],
+                               "rocprof_avg_launch_us": rocprof_avg,
+                               "rocprof_note": "rocprofv3 --kernel-trace --stats class average of the same command on this build "
+                                               "(profiles/r3_cfg2_kernel_stats.csv); null when the committed profile is of another build",
+                               "launches_per_evaluation": counts[k] // (10 if args.model == "mnist" else 3),
                                "share_of_denoiser_time": ms[k] / tot_ms}
         res["kernels"] = per
 

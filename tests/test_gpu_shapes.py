@@ -131,26 +131,47 @@ def test_results_do_not_depend_on_kernels_of_other_streams(sd):
     ya = torch.empty(32, 32, 32, 64, device=DEV)
     torch.cuda.synchronize()
 
-    def co_run(reps):
-        for _ in range(reps):
-            _lib.check(L.dm_conv2d(9, _lib.ptr(xa), 64, None, 0, _lib.ptr(wp), _lib.ptr(ba), 64, None, 0, 0.0, None, None, None, 0,
-                                   _lib.ptr(ya), None, 32, 16, 16, s2.cuda_stream))
+    # the co-runner stays RESIDENT for the whole forward - a background thread keeps its stream fed (at most 40
+    # launches queued) until the forwards under test have finished; 30 launches enqueued up front could drain before the
+    # Python-driven forward had enqueued its own kernels.
+    import threading
+    stop = threading.Event()
+    launched = [0]
+
+    def feeder():
+        while not stop.is_set():
+            for _ in range(20):
+                L.dm_conv2d(9, _lib.ptr(xa), 64, None, 0, _lib.ptr(wp), _lib.ptr(ba), 64, None, 0, 0.0, None, None, None, 0,
+                            _lib.ptr(ya), None, 32, 16, 16, s2.cuda_stream)
+            launched[0] += 20
+            s2.synchronize()
 
     d.set_seed(7)
     wide = d.UNetMini(image_size=64, in_channels=3, out_channels=3, model_channels=256, attention=True).eval()
     mb = d.UNetMini(image_size=32, precision="bf16").eval()
     mb.load_state_dict(sd)
     xw = torch.randn((2, 3, 64, 64), generator=g).to(DEV)
+    refs = []
     for name, mm, xx, trials in (("fp32", m, x, 20), ("bf16", mb, x, 10), ("wide + attention", wide, xw, 6)):
         with torch.cuda.stream(s1):
-            ref = mm(xx, t)
+            refs.append(mm(xx, t))
+    torch.cuda.synchronize()
+    th = threading.Thread(target=feeder, daemon=True)
+    th.start()
+    try:
+        for (name, mm, xx, trials), ref in zip((("fp32", m, x, 20), ("bf16", mb, x, 10), ("wide + attention", wide, xw, 6)), refs):
+            for trial in range(trials):
+                before = launched[0]
+                with torch.cuda.stream(s1):
+                    out = mm(xx, t)
+                s1.synchronize()
+                assert torch.equal(out, ref), (name, trial)
+                while launched[0] == before and th.is_alive():  # the co-runner did run beside this forward
+                    s1.synchronize()
+    finally:
+        stop.set()
+        th.join()
         torch.cuda.synchronize()
-        for trial in range(trials):
-            co_run(30)
-            with torch.cuda.stream(s1):
-                out = mm(xx, t)
-            torch.cuda.synchronize()
-            assert torch.equal(out, ref), (name, trial)
     # two sampling chains at once (each on its own stream and model instance) == each alone
     import diffusion_model_amd.sampler as sampler_mod
     m2 = d.UNetMini(image_size=32).eval()

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-3 measurement passes on the GPU box (run through gpurun from the repo root):
+#   bash tools/diag/r3_profiles.sh stats|traffic|sq
+# Every rocprofv3 pass is a run of its own (PMC passes never share a run with --stats / other counters' blocks).
+# Summaries: tools/diag/r3_summaries.py (run in the build container afterwards) -> profiles/r3_*.
+set -u
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/r3prof
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+case "$1" in
+stats)
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg2 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $O/prof_cfg2.json 2> $O/prof_cfg2.err || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg1 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-configs --sampler ancestral --ddim-steps 1000 --batch 64 > $O/prof_cfg1.json 2> $O/prof_cfg1.err || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg4 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs --precision bf16 --cfg > $O/prof_cfg4.json 2> $O/prof_cfg4.err || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg5 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-configs --model wide-attn --batch 256 > $O/prof_cfg5.json 2> $O/prof_cfg5.err || exit 1
+  ;;
+traffic)
+  timeout -s KILL 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-configs > $O/pmc_fetch.json 2> $O/pmc_fetch.err || exit 1
+  timeout -s KILL 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-configs > $O/pmc_write.json 2> $O/pmc_write.err || exit 1
+  ;;
+sq)
+  # SQ counters over one DDIM-50 pass (B=1024): MFMA-busy fraction and vector instructions per MFMA per kernel
+  timeout -s KILL 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_model -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-configs > $O/pmc_sq_model.json 2> $O/pmc_sq_model.err || exit 1
+  timeout -s KILL 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_cfg1 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-configs --sampler ancestral --ddim-steps 100 --batch 64 > $O/pmc_sq_cfg1.json 2> $O/pmc_sq_cfg1.err || exit 1
+  ;;
+esac
+echo done $1
