@@ -871,7 +871,7 @@ float* g_lowres_taps = nullptr;  // tests only (dm_debug_lowres_taps): where the
 // The fused low-resolution kernel (dm_kernels_lowres.hip) covers the 32x32 model with 64 channels in fp32 with the
 // three-term split-bf16 weight forms; a property of the model and the image size only, never of the batch.
 bool uses_lowres(const dm_unet* m, int H, int W) {
-  return m->lowres && tuned_geometry(m, H, W) && !m->bf16 && !m->attn && m->C == 64 && H == 32 && W == 32 && (m->x6 & 31) == 7;
+  return m->lowres && tuned_geometry(m, H, W) && !m->attn && m->C == 64 && H == 32 && W == 32 && (m->bf16 || (m->x6 & 31) == 7);
 }
 
 int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float* st2, int pin2, float cnt2, const float* heads,
@@ -886,19 +886,21 @@ int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float
     return L;
   };
   const BlockOff &d2b = m->blk[1], &d3 = m->blk[2], &u1 = m->blk[3], &u2b = m->blk[4];
+  // fp32 path: the three-term split-bf16 packs (*x); bf16 path: the (hi, lo) pair packs - the same order, two terms
+  const bool bf = m->bf16 != 0;
   a.t2 = t2; a.st2 = st2; a.pin2 = pin2; a.cnt2 = cnt2; a.g2 = P + d2b.g2; a.b2 = P + d2b.b2;
-  a.d2t = layer(d2b.trx, d2b.trb, 0, 0, false, -1);
-  a.d3c1 = layer(d3.c1x, d3.c1b, d3.g1, d3.b1, true, 2);
-  a.d3c2 = layer(d3.c2x, d3.c2b, d3.g2, d3.b2, true, -1);
-  a.d3t = layer(d3.trx, d3.trb, 0, 0, false, -1);
-  a.b0 = layer(m->o_b0x, m->o_b0b, m->o_bg, m->o_bb, true, -1);
-  a.b3 = layer(m->o_b3x, m->o_b3b, 0, 0, false, -1);
-  a.u1c1 = layer(u1.c1x, u1.c1b, u1.g1, u1.b1, true, 3);
-  a.u1c2 = layer(u1.c2x, u1.c2b, u1.g2, u1.b2, true, -1);
-  a.u1t = layer(u1.trx, u1.trb, 0, 0, false, -1);
-  a.u2c1 = layer(u2b.c1x, u2b.c1b, u2b.g1, u2b.b1, true, 4);
-  a.u2c2 = layer(u2b.c2x, u2b.c2b, u2b.g2, u2b.b2, true, -1);
-  a.u2t = layer(u2b.trx, u2b.trb, 0, 0, false, -1);
+  a.d2t = layer(bf ? d2b.tr : d2b.trx, d2b.trb, 0, 0, false, -1);
+  a.d3c1 = layer(bf ? d3.c1 : d3.c1x, d3.c1b, d3.g1, d3.b1, true, 2);
+  a.d3c2 = layer(bf ? d3.c2 : d3.c2x, d3.c2b, d3.g2, d3.b2, true, -1);
+  a.d3t = layer(bf ? d3.tr : d3.trx, d3.trb, 0, 0, false, -1);
+  a.b0 = layer(bf ? m->o_b0 : m->o_b0x, m->o_b0b, m->o_bg, m->o_bb, true, -1);
+  a.b3 = layer(bf ? m->o_b3 : m->o_b3x, m->o_b3b, 0, 0, false, -1);
+  a.u1c1 = layer(bf ? u1.c1 : u1.c1x, u1.c1b, u1.g1, u1.b1, true, 3);
+  a.u1c2 = layer(bf ? u1.c2 : u1.c2x, u1.c2b, u1.g2, u1.b2, true, -1);
+  a.u1t = layer(bf ? u1.tr : u1.trx, u1.trb, 0, 0, false, -1);
+  a.u2c1 = layer(bf ? u2b.c1 : u2b.c1x, u2b.c1b, u2b.g1, u2b.b1, true, 4);
+  a.u2c2 = layer(bf ? u2b.c2 : u2b.c2x, u2b.c2b, u2b.g2, u2b.b2, true, -1);
+  a.u2t = layer(bf ? u2b.tr : u2b.trx, u2b.trb, 0, 0, false, -1);
   a.heads = heads; a.heads_img_stride = heads_img_stride; a.heads_step_stride = heads_step_stride;
   a.step_ptr = step_ptr; a.step_off = step_off; a.d2 = d2; a.u2 = u2; a.B = B;
   a.taps = g_lowres_taps;
@@ -908,14 +910,16 @@ int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float
   static bool attr_done[DM_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_fused_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
   unsigned grid = 2u * cu_count(dev);  // persistent: two workgroups per CU (60 KB of LDS each), images n, n + grid, ...
   if (grid > (unsigned)B) grid = (unsigned)B;
   // algorithmic work of the twelve layers: 25,231,360 multiply-adds per image
   ProfScope ps(DM_K_LOWRES, s, 2.0 * 25231360.0 * B, 4.0 * B * (2.0 * 16 * 16 * 64 + 2.0 * 8 * 8 * 64) + 6.0 * 12.6 * 64 * 64 * 9);
-  hipLaunchKernelGGL(lowres_fused_kernel, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
+  if (bf) hipLaunchKernelGGL(lowres_fused_kernel<1>, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
+  else hipLaunchKernelGGL(lowres_fused_kernel<3>, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -17,6 +17,8 @@
 // one pixel and four runs of four consecutive channels.  Workgroup = 4 waves: at 8x8 as 2 (pixel halves) x 2 (channel
 // halves); at 4x4 (16 pixels: half a 32-row block) the pixel-half index splits K instead and the two partial sums meet
 // through LDS, or - transposed conv 4x4 -> 8x8 - it splits the four output parities.
+// NA = 1 is the bf16 path's form (BASELINE configs[3]): ONE bf16 activation plane, the weights as (hi, lo) bf16 pairs - the
+// first two terms of the same packing -, two MFMAs per product; input as IEEE half, output as bf16 like the layer kernels.
 // Chosen by the layer geometry only (C = 64, 32x32 images, fp32, no attention), never by the batch size: per-image results
 // do not depend on the batch an image rides in, so multi-GPU shards stay bit-identical to the unsharded run.
 #pragma once
@@ -31,7 +33,7 @@ struct LrLayer {
 };
 
 struct LowresArgs {
-  const float* t2;       // [B,16,16,64] raw output of down2.conv2
+  const float* t2;       // [B,16,16,64] raw output of down2.conv2 (bf16 path: IEEE half, 2 bytes per element)
   const float* st2;      // its GroupNorm statistics partials [B][pin2][8][2]
   int pin2; float cnt2;
   const float* g2; const float* b2;  // down2.bnorm2
@@ -41,7 +43,7 @@ struct LowresArgs {
   const float* heads; int heads_img_stride, heads_step_stride;  // [.., 6, 64] time-embedding heads (see unet_body)
   const int* step_ptr; int step_off;
   float* d2;             // [B,8,8,64] scratch: down2's raw output (skip input of up2.conv1)
-  float* u2;             // [B,16,16,64] up2's output
+  float* u2;             // [B,16,16,64] up2's output (bf16 path: bf16)
 #ifdef DM_STAMPS
   unsigned long long* stamps;  // diagnostic build only: s_memtime stamps [grid][32] at entry 2^20 (the conv kernels stamp the front of the buffer) of the phases of the workgroup's LAST image
 #endif
@@ -94,8 +96,9 @@ struct WS { const bf16_t* wp; size_t ts, so; };
 struct WFrag { uint4 q[4][3]; };  // the three split terms of the four 16-channel slabs of one tap
 
 // fetch the fragments of packed tap wt (L2): issued a whole layer epilogue ahead of their first use
-template <int NJ = 4>
+template <int NA, int NJ = 4>
 __device__ __forceinline__ void kload(WFrag& f, const WS& w, int wt, unsigned lane16) {
+  constexpr int NB = NA == 3 ? 3 : 2;  // weight terms: three-way split (fp32 path) / (hi, lo) pair (bf16 path)
   int opq = 0;
   asm volatile("" : "+v"(opq));  // (the address arithmetic stays here: see krun)
   lane16 += (unsigned)opq;
@@ -103,7 +106,7 @@ __device__ __forceinline__ void kload(WFrag& f, const WS& w, int wt, unsigned la
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < NB; ++s)
       f.q[j][s] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(w0 + s * w.so + (size_t)j * JS) + lane16);
 }
 
@@ -112,7 +115,7 @@ __device__ __forceinline__ void kload(WFrag& f, const WS& w, int wt, unsigned la
 // slab's pixel fragments (double buffer) and the L2 reads of the NEXT TAP's weight fragments into the slots just consumed (24
 // MFMAs ahead: one slab ahead, ~200 cycles, does not cover an L2 hit).  f: the fragments of tap 0 (kload).  ap: the lane's
 // fragment address in plane 0 at tap offset 0; tapf(t, aoff, wt): LDS offset and packed-weight tap of step t.
-template <class F>
+template <int NA, class F>
 __device__ __forceinline__ void krun(f32x16& acc, WFrag& f, const bf16_t* ap, int pl, const WS& w, unsigned lane16, int ntaps, F tapf) {
   constexpr int NJ = 4;
   // opaque copies: the fragment addresses are formed HERE, per call - left alone hipcc hoists the address arithmetic of all
@@ -125,7 +128,7 @@ __device__ __forceinline__ void krun(f32x16& acc, WFrag& f, const bf16_t* ap, in
   int aoff, wt;
   tapf(0, aoff, wt);
 #pragma unroll
-  for (int s = 0; s < 3; ++s) a[0][s] = *reinterpret_cast<const uint4*>(ap + s * pl + aoff);
+  for (int s = 0; s < NA; ++s) a[0][s] = *reinterpret_cast<const uint4*>(ap + s * pl + aoff);
 #pragma unroll 1
   for (int t = 0; t < ntaps; ++t) {
     int aoffn, wtn;
@@ -135,39 +138,38 @@ __device__ __forceinline__ void krun(f32x16& acc, WFrag& f, const bf16_t* ap, in
     for (int j = 0; j < NJ; ++j) {
       const int c = j & 1, nx = c ^ 1;
       const bf16_t* an = ap + ((j + 1 == NJ) ? aoffn : aoff + (j + 1) * 16);
-      const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, a[c][0]), a2 = __builtin_bit_cast(bf16x8_t, a[c][1]), a3 = __builtin_bit_cast(bf16x8_t, a[c][2]);
-      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, f.q[j][0]), b2 = __builtin_bit_cast(bf16x8_t, f.q[j][1]), b3 = __builtin_bit_cast(bf16x8_t, f.q[j][2]);
+      const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, a[c][0]);
+      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, f.q[j][0]), b2 = __builtin_bit_cast(bf16x8_t, f.q[j][1]);
       __builtin_amdgcn_sched_barrier(0);
-      // pixel terms a (B operand), weight terms b (A operand); products a1b3, a2b2, a1b2, a3b1, a2b1, a1b1 (small terms first)
-      LR_MFMA(b3, a1, acc, j & 1);
-#ifndef DM_LR_NOA
-      a[nx][0] = *reinterpret_cast<const uint4*>(an);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b2, a2, acc, j & 1);
-#ifndef DM_LR_NOA
-      a[nx][1] = *reinterpret_cast<const uint4*>(an + pl);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b2, a1, acc, j & 1);
-#ifndef DM_LR_NOA
-      a[nx][2] = *reinterpret_cast<const uint4*>(an + 2 * pl);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b1, a3, acc, j & 1);
-#ifndef DM_LR_NOB
-      f.q[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * w.so + (size_t)j * JS) + lane16);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b1, a2, acc, j & 1);
-#ifndef DM_LR_NOB
-      f.q[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + w.so + (size_t)j * JS) + lane16);
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b1, a1, acc, j & 1);
-#ifndef DM_LR_NOB
-      f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
-#endif
+      if constexpr (NA == 3) {
+        const bf16x8_t a2 = __builtin_bit_cast(bf16x8_t, a[c][1]), a3 = __builtin_bit_cast(bf16x8_t, a[c][2]);
+        const bf16x8_t b3 = __builtin_bit_cast(bf16x8_t, f.q[j][2]);
+        // pixel terms a (B operand), weight terms b (A operand); products a1b3, a2b2, a1b2, a3b1, a2b1, a1b1 (small terms first)
+        LR_MFMA(b3, a1, acc, j & 1);
+        a[nx][0] = *reinterpret_cast<const uint4*>(an);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b2, a2, acc, j & 1);
+        a[nx][1] = *reinterpret_cast<const uint4*>(an + pl);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b2, a1, acc, j & 1);
+        a[nx][2] = *reinterpret_cast<const uint4*>(an + 2 * pl);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b1, a3, acc, j & 1);
+        f.q[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * w.so + (size_t)j * JS) + lane16);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b1, a2, acc, j & 1);
+        f.q[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + w.so + (size_t)j * JS) + lane16);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b1, a1, acc, j & 1);
+        f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+      } else {  // bf16 activations x (hi, lo) weights: a1 lo, then a1 hi
+        LR_MFMA(b2, a1, acc, j & 1);
+        a[nx][0] = *reinterpret_cast<const uint4*>(an);
+        f.q[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + w.so + (size_t)j * JS) + lane16);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b1, a1, acc, j & 1);
+        f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     aoff = aoffn; wt = wtn;
@@ -179,7 +181,7 @@ __device__ __forceinline__ void krun(f32x16& acc, WFrag& f, const bf16_t* ap, in
 // L2 -> CU path of ~64 B/clk cannot deliver beside the MFMAs - and used for 12 MFMAs.  NJ = 2: the wave covers HALF of K
 // (channel slabs 2kh, 2kh+1 of every tap; caller offsets ap and w.wp) and the partial sums meet through LDS (kx_exchange);
 // NJ = 4: all of K.  ap0/ap1: the lane's fragment addresses for the two blocks.
-template <int NJ, class F>
+template <int NA, int NJ, class F>
 __device__ __forceinline__ void krun2(f32x16& acc0, f32x16& acc1, WFrag& f, const bf16_t* ap0, const bf16_t* ap1, int pl, const WS& w,
                                       unsigned lane16, int ntaps, F tapf) {
   static_assert(NJ == 2 || NJ == 4, "even slab count: the double buffer alternates per slab");
@@ -192,7 +194,7 @@ __device__ __forceinline__ void krun2(f32x16& acc0, f32x16& acc1, WFrag& f, cons
   int aoff, wt;
   tapf(0, aoff, wt);
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
+  for (int s = 0; s < NA; ++s) {
     a[0][0][s] = *reinterpret_cast<const uint4*>(ap0 + s * pl + aoff);
     a[0][1][s] = *reinterpret_cast<const uint4*>(ap1 + s * pl + aoff);
   }
@@ -207,41 +209,57 @@ __device__ __forceinline__ void krun2(f32x16& acc0, f32x16& acc1, WFrag& f, cons
       const int no = (j + 1 == NJ) ? aoffn : aoff + (j + 1) * 16;
       const bf16_t* an0 = ap0 + no;
       const bf16_t* an1 = ap1 + no;
-      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, f.q[j][0]), b2 = __builtin_bit_cast(bf16x8_t, f.q[j][1]), b3 = __builtin_bit_cast(bf16x8_t, f.q[j][2]);
-      const bf16x8_t p1 = __builtin_bit_cast(bf16x8_t, a[c][0][0]), p2 = __builtin_bit_cast(bf16x8_t, a[c][0][1]), p3 = __builtin_bit_cast(bf16x8_t, a[c][0][2]);
-      const bf16x8_t q1 = __builtin_bit_cast(bf16x8_t, a[c][1][0]), q2 = __builtin_bit_cast(bf16x8_t, a[c][1][1]), q3 = __builtin_bit_cast(bf16x8_t, a[c][1][2]);
+      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, f.q[j][0]), b2 = __builtin_bit_cast(bf16x8_t, f.q[j][1]);
+      const bf16x8_t p1 = __builtin_bit_cast(bf16x8_t, a[c][0][0]), q1 = __builtin_bit_cast(bf16x8_t, a[c][1][0]);
       __builtin_amdgcn_sched_barrier(0);
-      // products a1b3, a2b2, a1b2, a3b1, a2b1, a1b1 (small terms first), block 0 then block 1; one memory instruction behind
-      // each of the first nine MFMAs: the next slab's six pixel fragments (LDS), then the next tap's weight fragments (L2)
-      LR_MFMA(b3, p1, acc0, j & 1);
-      a[nx][0][0] = *reinterpret_cast<const uint4*>(an0);
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b3, q1, acc1, j & 1);
-      a[nx][1][0] = *reinterpret_cast<const uint4*>(an1);
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b2, p2, acc0, j & 1);
-      a[nx][0][1] = *reinterpret_cast<const uint4*>(an0 + pl);
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b2, q2, acc1, j & 1);
-      a[nx][1][1] = *reinterpret_cast<const uint4*>(an1 + pl);
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b2, p1, acc0, j & 1);
-      a[nx][0][2] = *reinterpret_cast<const uint4*>(an0 + 2 * pl);
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b2, q1, acc1, j & 1);
-      a[nx][1][2] = *reinterpret_cast<const uint4*>(an1 + 2 * pl);
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b1, p3, acc0, j & 1);
-      f.q[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * w.so + (size_t)j * JS) + lane16);
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b1, q3, acc1, j & 1);
-      f.q[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + w.so + (size_t)j * JS) + lane16);
-      __builtin_amdgcn_sched_barrier(0);
-      LR_MFMA(b1, p2, acc0, j & 1);
-      LR_MFMA(b1, q2, acc1, j & 1);
-      LR_MFMA(b1, p1, acc0, j & 1);
-      LR_MFMA(b1, q1, acc1, j & 1);
-      f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+      if constexpr (NA == 3) {
+        const bf16x8_t b3 = __builtin_bit_cast(bf16x8_t, f.q[j][2]);
+        const bf16x8_t p2 = __builtin_bit_cast(bf16x8_t, a[c][0][1]), p3 = __builtin_bit_cast(bf16x8_t, a[c][0][2]);
+        const bf16x8_t q2 = __builtin_bit_cast(bf16x8_t, a[c][1][1]), q3 = __builtin_bit_cast(bf16x8_t, a[c][1][2]);
+        // products a1b3, a2b2, a1b2, a3b1, a2b1, a1b1 (small terms first), block 0 then block 1; one memory instruction behind
+        // each of the first nine MFMAs: the next slab's six pixel fragments (LDS), then the next tap's weight fragments (L2)
+        LR_MFMA(b3, p1, acc0, j & 1);
+        a[nx][0][0] = *reinterpret_cast<const uint4*>(an0);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b3, q1, acc1, j & 1);
+        a[nx][1][0] = *reinterpret_cast<const uint4*>(an1);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b2, p2, acc0, j & 1);
+        a[nx][0][1] = *reinterpret_cast<const uint4*>(an0 + pl);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b2, q2, acc1, j & 1);
+        a[nx][1][1] = *reinterpret_cast<const uint4*>(an1 + pl);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b2, p1, acc0, j & 1);
+        a[nx][0][2] = *reinterpret_cast<const uint4*>(an0 + 2 * pl);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b2, q1, acc1, j & 1);
+        a[nx][1][2] = *reinterpret_cast<const uint4*>(an1 + 2 * pl);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b1, p3, acc0, j & 1);
+        f.q[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * w.so + (size_t)j * JS) + lane16);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b1, q3, acc1, j & 1);
+        f.q[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + w.so + (size_t)j * JS) + lane16);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b1, p2, acc0, j & 1);
+        LR_MFMA(b1, q2, acc1, j & 1);
+        LR_MFMA(b1, p1, acc0, j & 1);
+        LR_MFMA(b1, q1, acc1, j & 1);
+        f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+      } else {  // bf16 activations x (hi, lo) weights
+        LR_MFMA(b2, p1, acc0, j & 1);
+        a[nx][0][0] = *reinterpret_cast<const uint4*>(an0);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b2, q1, acc1, j & 1);
+        a[nx][1][0] = *reinterpret_cast<const uint4*>(an1);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b1, p1, acc0, j & 1);
+        f.q[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + w.so + (size_t)j * JS) + lane16);
+        __builtin_amdgcn_sched_barrier(0);
+        LR_MFMA(b1, q1, acc1, j & 1);
+        f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     aoff = aoffn; wt = wtn;
@@ -346,10 +364,18 @@ __device__ __forceinline__ void gn_silu_regs(f32x16& acc, bool valid, float inv_
 }
 
 // the lane's 16 values -> three bf16 planes at pixel index pix of a plane buffer (plane stride pl)
+template <int NA>
 __device__ __forceinline__ void put_planes(const f32x16& acc, bf16_t* buf, int pl, int pix, int cb) {
   bf16_t* q = buf + pix * RSB + cb;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+    if constexpr (NA == 1) {  // one plane: round to nearest even
+      uint2 s1;
+      s1.x = (unsigned)f2bf(acc[4 * k]) | ((unsigned)f2bf(acc[4 * k + 1]) << 16);
+      s1.y = (unsigned)f2bf(acc[4 * k + 2]) | ((unsigned)f2bf(acc[4 * k + 3]) << 16);
+      *reinterpret_cast<uint2*>(q + 8 * k) = s1;
+      continue;
+    }
     uint2 s1, s2, s3;
     dm_split3(acc[4 * k], acc[4 * k + 1], s1.x, s2.x, s3.x);
     dm_split3(acc[4 * k + 2], acc[4 * k + 3], s1.y, s2.y, s3.y);
@@ -360,7 +386,15 @@ __device__ __forceinline__ void put_planes(const f32x16& acc, bf16_t* buf, int p
 }
 
 // eight fp32 values (two float4) -> three bf16 planes, 16 bytes each, at q
+template <int NA>
 __device__ __forceinline__ void put_planes8(float4 w0, float4 w1, bf16_t* q, int pl) {
+  if constexpr (NA == 1) {
+    uint4 s1;
+    s1.x = (unsigned)f2bf(w0.x) | ((unsigned)f2bf(w0.y) << 16); s1.y = (unsigned)f2bf(w0.z) | ((unsigned)f2bf(w0.w) << 16);
+    s1.z = (unsigned)f2bf(w1.x) | ((unsigned)f2bf(w1.y) << 16); s1.w = (unsigned)f2bf(w1.z) | ((unsigned)f2bf(w1.w) << 16);
+    *reinterpret_cast<uint4*>(q) = s1;
+    return;
+  }
   uint4 s1, s2, s3;
   dm_split3(w0.x, w0.y, s1.x, s2.x, s3.x);
   dm_split3(w0.z, w0.w, s1.y, s2.y, s3.y);
@@ -371,6 +405,17 @@ __device__ __forceinline__ void put_planes8(float4 w0, float4 w1, bf16_t* q, int
   *reinterpret_cast<uint4*>(q + 2 * pl) = s3;
 }
 
+// the lane's 16 values as bf16 at q (+ 8k per run): the bf16 path's 16-bit storage of a tensor its consumer reads raw
+__device__ __forceinline__ void put_bf16(const f32x16& acc, bf16_t* q) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    uint2 v;
+    v.x = (unsigned)f2bf(acc[4 * k]) | ((unsigned)f2bf(acc[4 * k + 1]) << 16);
+    v.y = (unsigned)f2bf(acc[4 * k + 2]) | ((unsigned)f2bf(acc[4 * k + 3]) << 16);
+    *reinterpret_cast<uint2*>(q + 8 * k) = v;
+  }
+}
+
 // the lane's 16 values as fp32 at q (+ 8k per run)
 __device__ __forceinline__ void put_f32(const f32x16& acc, float* q) {
 #pragma unroll
@@ -378,23 +423,24 @@ __device__ __forceinline__ void put_f32(const f32x16& acc, float* q) {
 }
 
 // zero the given pixel rows (all three planes) of a plane buffer: idx -> pixel index through f
-template <class F>
+template <int NA, class F>
 __device__ __forceinline__ void zero_pixels(bf16_t* buf, int pl, int npix, F pixf) {
-  for (int i = threadIdx.x; i < npix * 27; i += 256) {  // 3 planes x 9 uint4 per pixel row
-    const int pp = i / 27, r = i - pp * 27, s = r / 9, u = r - s * 9;
+  for (int i = threadIdx.x; i < npix * 9 * NA; i += 256) {  // NA planes x 9 uint4 per pixel row
+    const int pp = i / (9 * NA), r = i - pp * (9 * NA), s = r / 9, u = r - s * 9;
     *reinterpret_cast<uint4*>(buf + s * pl + pixf(pp) * RSB + u * 8) = make_uint4(0u, 0u, 0u, 0u);
   }
 }
 // halo ring of an N x N layout with an (N-2) x (N-2) interior
-template <int N>
+template <int NA, int N>
 __device__ __forceinline__ void zero_ring(bf16_t* buf, int pl) {
-  zero_pixels(buf, pl, 4 * (N - 1), [](int i) {
+  zero_pixels<NA>(buf, pl, 4 * (N - 1), [](int i) {
     const int side = i / (N - 1), k = i - side * (N - 1);
     return side == 0 ? k : side == 1 ? (N - 1) * N + 1 + k : side == 2 ? (1 + k) * N : k * N + N - 1;
   });
 }
 }  // namespace lr
 
+template <int NA>
 __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p) {
   using namespace lr;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -453,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
   WFrag wf;
   // taps of the input phase (a, b) of a stride-2 conv: ky = 2ty + 1 - a, kx = 2tx + 1 - b
   auto wt_phase = [](int pa, int pb, int ty, int tx) { return (2 * ty + 1 - pa) * 4 + 2 * tx + 1 - pb; };
-  if (blockIdx.x < p.B) kload<2>(wf, w_d2t, wt_phase(0, 0, 0, 0), lane16);
+  if (blockIdx.x < p.B) kload<NA, 2>(wf, w_d2t, wt_phase(0, 0, 0, 0), lane16);
   // the lane's fragment offsets for the two 32-pixel blocks of an 8x8 layer (pixel b*32 + l31), K half kh = wm
   const int y8a = l31 >> 3, y8b = 4 + (l31 >> 3), x8l = l31 & 7;
   const int kh_el = wm * 32;  // first channel of the wave's K half
@@ -489,6 +535,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     zero_acc(acc);
     zero_acc(acc1);
     const float* src = p.t2 + (size_t)n * 16 * 16 * 64;
+    const bf16_t* srch = reinterpret_cast<const bf16_t*>(p.t2) + (size_t)n * 16 * 16 * 64;  // (NA = 1: the tensor is IEEE half)
     float4 v0[3], v1[3];
     unsigned inbm = 0;
     // the three (pixel, channel octet) items of this thread for phase ph: loads from clamped addresses, padding by a mask
@@ -502,9 +549,13 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
         const int Y = pix / 9, Xc = pix - Y * 9;
         const int iy = 2 * Y - pa, ix = 2 * Xc - pb;
         inbm |= ((unsigned)iy < 16u && (unsigned)ix < 16u) ? (1u << u) : 0u;
-        const float* q = src + ((min(max(iy, 0), 15) * 16 + min(max(ix, 0), 15)) * 64 + c8 * 8);
-        v0[u] = *reinterpret_cast<const float4*>(q);
-        v1[u] = *reinterpret_cast<const float4*>(q + 4);
+        const int eo = (min(max(iy, 0), 15) * 16 + min(max(ix, 0), 15)) * 64 + c8 * 8;
+        if constexpr (NA == 1) {
+          v0[u] = __builtin_bit_cast(float4, *reinterpret_cast<const uint4*>(srch + eo));  // eight halves, widened when staged
+        } else {
+          v0[u] = *reinterpret_cast<const float4*>(src + eo);
+          v1[u] = *reinterpret_cast<const float4*>(src + eo + 4);
+        }
       }
     };
     fetch(0);
@@ -517,27 +568,32 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
         if (idx < 81 * 8) {
           const int pix = idx >> 3, c8 = idx & 7;
           float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+          if constexpr (NA == 1) {
+            const uint4 hv = __builtin_bit_cast(uint4, v0[u]);
+            v0[u] = make_float4(h2f((bf16_t)(hv.x & 0xffff)), h2f((bf16_t)(hv.x >> 16)), h2f((bf16_t)(hv.y & 0xffff)), h2f((bf16_t)(hv.y >> 16)));
+            v1[u] = make_float4(h2f((bf16_t)(hv.z & 0xffff)), h2f((bf16_t)(hv.z >> 16)), h2f((bf16_t)(hv.w & 0xffff)), h2f((bf16_t)(hv.w >> 16)));
+          }
           if ((inbm >> u) & 1) {
             const float4 sc0 = *reinterpret_cast<const float4*>(s_scale + c8 * 8), sc1 = *reinterpret_cast<const float4*>(s_scale + c8 * 8 + 4);
             const float4 sh0 = *reinterpret_cast<const float4*>(s_shift + c8 * 8), sh1 = *reinterpret_cast<const float4*>(s_shift + c8 * 8 + 4);
             w0 = dm_silu_add4(make_float4(fmaf(v0[u].x, sc0.x, sh0.x), fmaf(v0[u].y, sc0.y, sh0.y), fmaf(v0[u].z, sc0.z, sh0.z), fmaf(v0[u].w, sc0.w, sh0.w)), make_float4(0.f, 0.f, 0.f, 0.f));
             w1 = dm_silu_add4(make_float4(fmaf(v1[u].x, sc1.x, sh1.x), fmaf(v1[u].y, sc1.y, sh1.y), fmaf(v1[u].z, sc1.z, sh1.z), fmaf(v1[u].w, sc1.w, sh1.w)), make_float4(0.f, 0.f, 0.f, 0.f));
           }
-          put_planes8(w0, w1, P + pix * RSB + c8 * 8, PL);
+          put_planes8<NA>(w0, w1, P + pix * RSB + c8 * 8, PL);
         }
       }
       if (ph < 3) fetch(ph + 1);  // the next phase's pixels travel while this phase's MFMAs run
       __syncthreads();
-      krun2<2>(acc, acc1, wf, P + (y8a * 9 + x8l) * RSB + 8 * h + kh_el, P + (y8b * 9 + x8l) * RSB + 8 * h + kh_el, PL, w_d2t, lane16, 4,
+      krun2<NA, 2>(acc, acc1, wf, P + (y8a * 9 + x8l) * RSB + 8 * h + kh_el, P + (y8b * 9 + x8l) * RSB + 8 * h + kh_el, PL, w_d2t, lane16, 4,
                [&](int t, int& ao, int& wt) { ao = ((t >> 1) * 9 + (t & 1)) * RSB; wt = wt_phase(pa, pb, t >> 1, t & 1); });
-      if (ph < 3) kload<2>(wf, w_d2t, wt_phase((ph + 1) >> 1, (ph + 1) & 1, 0, 0), lane16);
+      if (ph < 3) kload<NA, 2>(wf, w_d2t, wt_phase((ph + 1) >> 1, (ph + 1) & 1, 0, 0), lane16);
     }
-    kload<2>(wf, w_d3c1, 0, lane16);
+    kload<NA, 2>(wf, w_d3c1, 0, lane16);
     kx_exchange(acc, acc1, wm, wave, lane, X8);  // (its barrier: every wave is done reading the phase planes)
     add_bias(acc, bias_t + 0 * 64, cb);
     put_f32(acc, p.d2 + ((size_t)n * 64 + m8) * 64 + cb);  // down2's output, raw: skip input of up2.conv1, read back by this workgroup
-    zero_ring<10>(P, PL);
-    put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);  // ... and, as planes, the input of down3.conv1
+    zero_ring<NA, 10>(P, PL);
+    put_planes<NA>(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);  // ... and, as planes, the input of down3.conv1
 
     LR_STAMP(1);
     // ================= B, C: down3.conv1, down3.conv2, Conv2d 3x3 p1 at 8x8 (model.py:54-62) =================
@@ -548,30 +604,30 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     zero_acc(acc);
     zero_acc(acc1);
     LR_STAMP(13);
-    krun2<2>(acc, acc1, wf, a8a, a8b, PL, w_d3c1, lane16, 9, tap3_10);
+    krun2<NA, 2>(acc, acc1, wf, a8a, a8b, PL, w_d3c1, lane16, 9, tap3_10);
     LR_STAMP(14);
-    kload<2>(wf, w_d3c2, 0, lane16);
+    kload<NA, 2>(wf, w_d3c2, 0, lane16);
     kx_exchange(acc, acc1, wm, wave, lane, X8);
     add_bias(acc, bias_t + 1 * 64, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 0 * 64, sm + SM_BETA + 0 * 64, sm + SM_TEMB + 0 * 64, cb, red, wave, wn);
     LR_STAMP(15);
     // (the two barriers inside: every wave is past its K loop, P may be rewritten; the halo ring stays zero)
-    put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
+    put_planes<NA>(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
     LR_STAMP(2);
     __syncthreads();
     zero_acc(acc);
     zero_acc(acc1);
-    krun2<2>(acc, acc1, wf, a8a, a8b, PL, w_d3c2, lane16, 9, tap3_10);
-    kload(wf, w_d3t, wt_phase(wm_s, 0, 0, 0), lane16);
+    krun2<NA, 2>(acc, acc1, wf, a8a, a8b, PL, w_d3c2, lane16, 9, tap3_10);
+    kload<NA>(wf, w_d3t, wt_phase(wm_s, 0, 0, 0), lane16);
     kx_exchange(acc, acc1, wm, wave, lane, X8);
     add_bias(acc, bias_t + 2 * 64, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 1 * 64, sm + SM_BETA + 1 * 64, nullptr, cb, red, wave, wn);
     // output in the four-phase layout of the stride-2 conv: input pixel (y, x) = (2Y - a, 2X - b) -> plane (a, b) pixel (Y, X) of 5x5
     {
       const int pa = y8 & 1, pb = x8 & 1;
-      put_planes(acc, P, PL, (pa * 2 + pb) * 25 + ((y8 + pa) >> 1) * 5 + ((x8 + pb) >> 1), cb);
+      put_planes<NA>(acc, P, PL, (pa * 2 + pb) * 25 + ((y8 + pa) >> 1) * 5 + ((x8 + pb) >> 1), cb);
       // padding: row Y = 4 of the planes with a = 0 (input row 8), row Y = 0 with a = 1 (input row -1); columns alike
-      zero_pixels(P, PL, 36, [](int i) {
+      zero_pixels<NA>(P, PL, 36, [](int i) {
         const int ph = i / 9, k = i - ph * 9, a = ph >> 1, b = ph & 1;
         const int Yp = a ? 0 : 4, Xp = b ? 0 : 4;
         return ph * 25 + (k < 5 ? Yp * 5 + k : ((k - 5) + (Yp == 0 ? 1 : 0)) * 5 + Xp);
@@ -582,27 +638,27 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     // ================= D: down3.transform, Conv2d 4x4 s2 p1, 8x8 -> 4x4: K split by input phase over the wave pairs =================
     __syncthreads();
     zero_acc(acc);
-    krun(acc, wf, P + (y4 * 5 + x4) * RSB + 8 * h, PL, w_d3t, lane16, 8, [&](int t, int& ao, int& wt) {
+    krun<NA>(acc, wf, P + (y4 * 5 + x4) * RSB + 8 * h, PL, w_d3t, lane16, 8, [&](int t, int& ao, int& wt) {
       const int ph = 2 * wm_s + (t >> 2), ty = (t >> 1) & 1, tx = t & 1;
       ao = (ph * 25 + ty * 5 + tx) * RSB;
       wt = wt_phase(ph >> 1, ph & 1, ty, tx);
     });
-    kload(wf, w_b0, 5 * wm_s, lane16);
+    kload<NA>(wf, w_b0, 5 * wm_s, lane16);
     __syncthreads();  // P is dead: the 4x4-level buffers E, F and the exchange area take its place
     if (wm) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) X[(wn * 16 + r) * 64 + lane] = acc[r];
     }
-    zero_ring<6>(E, PL4);
-    zero_ring<6>(Fb, PL4);
-    zero_ring<6>(D3p, PL4);  // (the buffer served as the 8x8 level's exchange area)
+    zero_ring<NA, 6>(E, PL4);
+    zero_ring<NA, 6>(Fb, PL4);
+    zero_ring<NA, 6>(D3p, PL4);  // (the buffer served as the 8x8 level's exchange area)
     __syncthreads();
     const int pix6 = (y4 + 1) * 6 + x4 + 1;
     if (!wm) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += X[(wn * 16 + r) * 64 + lane];
       add_bias(acc, bias_t + 3 * 64, cb);
-      if (v4) put_planes(acc, D3p, PL4, pix6, cb);  // down3's output, raw: input of bottleneck.0 and skip input of up1.conv1
+      if (v4) put_planes<NA>(acc, D3p, PL4, pix6, cb);  // down3's output, raw: input of bottleneck.0 and skip input of up1.conv1
       if (p.taps && v4) put_f32(acc, p.taps + (size_t)n * 6144 + m4 * 64 + cb);
     }
 
@@ -617,9 +673,9 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       __syncthreads();  // the input planes are complete; the exchange area is free
       zero_acc(acc);
       const int a4 = (y4 * 6 + x4) * RSB + 8 * h;
-      if (in1) krun(acc, wf, (wm_s ? in1 : in0) + a4, PL4, ws, lane16, 9, tap3_6);
-      else krun(acc, wf, in0 + a4, PL4, ws, lane16, wm_s ? 4 : 5, [&](int t, int& ao, int& wt) { tap3_6(t + 5 * wm_s, ao, wt); });
-      kload(wf, wsn, wtn0, lane16);
+      if (in1) krun<NA>(acc, wf, (wm_s ? in1 : in0) + a4, PL4, ws, lane16, 9, tap3_6);
+      else krun<NA>(acc, wf, in0 + a4, PL4, ws, lane16, wm_s ? 4 : 5, [&](int t, int& ao, int& wt) { tap3_6(t + 5 * wm_s, ao, wt); });
+      kload<NA>(wf, wsn, wtn0, lane16);
       if (wm) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) X[(wn * 16 + r) * 64 + lane] = acc[r];
@@ -630,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
         for (int r = 0; r < 16; ++r) acc[r] += X[(wn * 16 + r) * 64 + lane];
         add_bias(acc, bias_t + li * 64, cb);
         if (ni >= 0) gn_silu_regs<1>(acc, v4, 1.0f / 128.0f, sm + SM_GAMMA + ni * 64, sm + SM_BETA + ni * 64, temb, cb, red, wave, wn);
-        if (v4) put_planes(acc, out, PL4, pix6, cb);
+        if (v4) put_planes<NA>(acc, out, PL4, pix6, cb);
         if (tap_off >= 0 && p.taps && v4) put_f32(acc, p.taps + (size_t)n * 6144 + tap_off + m4 * 64 + cb);
       }
     };
@@ -651,11 +707,11 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     {
       const bf16_t* au = Fb + (y4 * 6 + x4) * RSB + 8 * h;
       const int par0 = 2 * wm_s;
-      krun(acc, wf, au, PL4, w_u1t, lane16, 4, [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + (t & 1)) * RSB; wt = par0 * 4 + t; });
-      kload(wf, w_u1t, (par0 + 1) * 4, lane16);
-      krun(acc1, wf, au, PL4, w_u1t, lane16, 4, [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + 1 + (t & 1)) * RSB; wt = (par0 + 1) * 4 + t; });
+      krun<NA>(acc, wf, au, PL4, w_u1t, lane16, 4, [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + (t & 1)) * RSB; wt = par0 * 4 + t; });
+      kload<NA>(wf, w_u1t, (par0 + 1) * 4, lane16);
+      krun<NA>(acc1, wf, au, PL4, w_u1t, lane16, 4, [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + 1 + (t & 1)) * RSB; wt = (par0 + 1) * 4 + t; });
     }
-    kload<2>(wf, w_u2c1a, 0, lane16);
+    kload<NA, 2>(wf, w_u2c1a, 0, lane16);
     add_bias(acc, bias_t + 8 * 64, cb);
     add_bias(acc1, bias_t + 8 * 64, cb);
     if (p.taps && v4) {
@@ -663,10 +719,10 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       put_f32(acc1, p.taps + (size_t)n * 6144 + 2048 + ((2 * y4 + wm) * 8 + 2 * x4 + 1) * 64 + cb);
     }
     __syncthreads();  // every wave is done with F: P becomes the 10x10 layout again
-    zero_ring<10>(P, PL);
+    zero_ring<NA, 10>(P, PL);
     if (v4) {  // up1's output, raw: first input of up2.conv1 (parity py = wm, px = 0 / 1)
-      put_planes(acc, P, PL, (2 * y4 + wm + 1) * 10 + 2 * x4 + 1, cb);
-      put_planes(acc1, P, PL, (2 * y4 + wm + 1) * 10 + 2 * x4 + 2, cb);
+      put_planes<NA>(acc, P, PL, (2 * y4 + wm + 1) * 10 + 2 * x4 + 1, cb);
+      put_planes<NA>(acc1, P, PL, (2 * y4 + wm + 1) * 10 + 2 * x4 + 2, cb);
     }
 
     LR_STAMP(9);
@@ -682,31 +738,31 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       d2v[u][0] = *reinterpret_cast<const float4*>(q);
       d2v[u][1] = *reinterpret_cast<const float4*>(q + 4);
     }
-    krun2<2>(acc, acc1, wf, a8a, a8b, PL, w_u2c1a, lane16, 9, tap3_10);
-    kload<2>(wf, w_u2c1b, 0, lane16);
+    krun2<NA, 2>(acc, acc1, wf, a8a, a8b, PL, w_u2c1a, lane16, 9, tap3_10);
+    kload<NA, 2>(wf, w_u2c1b, 0, lane16);
     __syncthreads();  // the up1 planes are consumed
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int idx = tid + 256 * u, pix = idx >> 3, c8 = idx & 7;
-      put_planes8(d2v[u][0], d2v[u][1], P + (((pix >> 3) + 1) * 10 + (pix & 7) + 1) * RSB + c8 * 8, PL);
+      put_planes8<NA>(d2v[u][0], d2v[u][1], P + (((pix >> 3) + 1) * 10 + (pix & 7) + 1) * RSB + c8 * 8, PL);
     }
     __syncthreads();
-    krun2<2>(acc, acc1, wf, a8a, a8b, PL, w_u2c1b, lane16, 9, tap3_10);
-    kload<2>(wf, w_u2c2, 0, lane16);
+    krun2<NA, 2>(acc, acc1, wf, a8a, a8b, PL, w_u2c1b, lane16, 9, tap3_10);
+    kload<NA, 2>(wf, w_u2c2, 0, lane16);
     kx_exchange(acc, acc1, wm, wave, lane, X8);
     add_bias(acc, bias_t + 9 * 64, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 5 * 64, sm + SM_BETA + 5 * 64, sm + SM_TEMB + 2 * 64, cb, red, wave, wn);
-    put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
+    put_planes<NA>(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
     LR_STAMP(10);
     __syncthreads();
     zero_acc(acc);
     zero_acc(acc1);
-    krun2<2>(acc, acc1, wf, a8a, a8b, PL, w_u2c2, lane16, 9, tap3_10);
-    kload(wf, w_u2t, 2 * wm_s * 4, lane16);
+    krun2<NA, 2>(acc, acc1, wf, a8a, a8b, PL, w_u2c2, lane16, 9, tap3_10);
+    kload<NA>(wf, w_u2t, 2 * wm_s * 4, lane16);
     kx_exchange(acc, acc1, wm, wave, lane, X8);
     add_bias(acc, bias_t + 10 * 64, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 6 * 64, sm + SM_BETA + 6 * 64, nullptr, cb, red, wave, wn);
-    put_planes(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
+    put_planes<NA>(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
 
     LR_STAMP(11);
     // ================= L: up2.transform, ConvTranspose2d 4x4 s2 p1, 8x8 -> 16x16: output parities 2wm, 2wm+1 per wave pair =================
@@ -719,14 +775,21 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
         const int par = 2 * wm_s + pp, py = wm_s, px = pp;
         zero_acc(acc);
         zero_acc(acc1);
-        krun2<4>(acc, acc1, wf, u8a, u8b, PL, w_u2t, lane16, 4,
+        krun2<NA, 4>(acc, acc1, wf, u8a, u8b, PL, w_u2t, lane16, 4,
                  [&](int t, int& ao, int& wt) { ao = ((py + (t >> 1)) * 10 + px + (t & 1)) * RSB; wt = par * 4 + t; });
-        if (pp == 0) kload(wf, w_u2t, (par + 1) * 4, lane16);
-        else if (n + (int)gridDim.x < p.B) kload<2>(wf, w_d2t, wt_phase(0, 0, 0, 0), lane16);  // the next image's first fragments
+        if (pp == 0) kload<NA>(wf, w_u2t, (par + 1) * 4, lane16);
+        else if (n + (int)gridDim.x < p.B) kload<NA, 2>(wf, w_d2t, wt_phase(0, 0, 0, 0), lane16);  // the next image's first fragments
         add_bias(acc, bias_t + 11 * 64, cb);
         add_bias(acc1, bias_t + 11 * 64, cb);
-        put_f32(acc, p.u2 + (((size_t)n * 16 + 2 * y8a + py) * 16 + 2 * x8l + px) * 64 + cb);
-        put_f32(acc1, p.u2 + (((size_t)n * 16 + 2 * y8b + py) * 16 + 2 * x8l + px) * 64 + cb);
+        const size_t oa = (((size_t)n * 16 + 2 * y8a + py) * 16 + 2 * x8l + px) * 64 + cb;
+        const size_t ob = (((size_t)n * 16 + 2 * y8b + py) * 16 + 2 * x8l + px) * 64 + cb;
+        if constexpr (NA == 1) {
+          put_bf16(acc, reinterpret_cast<bf16_t*>(p.u2) + oa);
+          put_bf16(acc1, reinterpret_cast<bf16_t*>(p.u2) + ob);
+        } else {
+          put_f32(acc, p.u2 + oa);
+          put_f32(acc1, p.u2 + ob);
+        }
       }
     }
     LR_STAMP(12);
