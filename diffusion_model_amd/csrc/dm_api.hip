@@ -526,6 +526,12 @@ size_t max_stats_partials(int H, int W, int C) {
 // Everything else the reference accepts (H, W divisible by 8; C divisible by 8) runs on dm_kernels_generic.hip.
 bool tuned_geometry(const dm_unet* m, int H, int W) { return m->fast && is_pow2(H) && is_pow2(W) && H >= 8 && W >= 8; }
 
+// Is the sampler update folded into final_conv's store (FinalStep)?  fp32, C = 64, tuned geometry, no guidance (the caller's part).
+bool fuses_step(const dm_unet* m, int H, int W) {
+  static const bool off = getenv("DM_DEBUG_NO_STEP_FUSION") != nullptr;  // diagnostics only
+  return !off && tuned_geometry(m, H, W) && !m->bf16 && m->C == 64 && m->Cin == m->Cout;
+}
+
 // Carve the workspace for a denoiser batch B (all offsets 256-B aligned).  Everything whose
 // address a captured graph bakes in and whose size does not depend on the number of steps
 // comes first, so those addresses are a function of (B, H, W) only; the step-count-dependent
@@ -568,7 +574,8 @@ Workspace carve(const dm_unet* m, void* base, int B, int H, int W, int nsteps, s
 }
 
 int launch_final(const float* u, int bf16, const float* stats, int pin, float cnt, const float* gamma, const float* beta,
-                 const float* wt, const float* bias, float* out, int B, int H, int W, int C, int Cout, hipStream_t s);
+                 const float* wt, const float* bias, float* out, int B, int H, int W, int C, int Cout, hipStream_t s,
+                 const FinalStep* fs = nullptr);
 
 int check_geometry(const dm_unet* m, int B, int H, int W) {
   if (B <= 0) return fail("batch must be positive (got %d)", B);
@@ -932,8 +939,9 @@ int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float
 // layers, which see no time / class embedding, are evaluated once and read by both halves.
 int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, const float* heads,
               int heads_img_stride, int heads_step_stride, const int* step_ptr, int step_off,
-              const Workspace& w, int B, int H, int W, hipStream_t s, int dup_half = 0) {
+              const Workspace& w, int B, int H, int W, hipStream_t s, int dup_half = 0, const FinalStep* fstep = nullptr) {
   const int C = m->C;
+  if (fstep && !fuses_step(m, H, W)) return fail("internal: fused sampler update requested for a path without it");
   if (!tuned_geometry(m, H, W))
     return unet_body_generic(m, P, x, eps, heads, heads_img_stride, heads_step_stride, step_ptr, step_off, w, B, H, W, s);
   // init_conv (model.py:135) is folded into down1.conv1's staging (no kernel, no HBM round trip)
@@ -1018,7 +1026,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     if (block(5, w.U2, w.D1, H / 2, W / 2, true, w.A0, w.SA)) return 1;
     const ConvGeo pf = conv_geo(2, H / 2, W / 2, C);
     return launch_final(w.A0, m->bf16, w.SA, pf.pout, pf.cnt_out, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H, W, C,
-                        m->Cout, s);
+                        m->Cout, s, fstep);
   }
   if (block(1, w.D1, nullptr, H / 2, W / 2, false, w.D2, m->attn ? w.SA : nullptr)) return 1;
   if (m->attn) {
@@ -1047,15 +1055,22 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   {  // final_conv (model.py:111-115,151)
     const ConvGeo pg = conv_geo(2, H / 2, W / 2, C);
     if (launch_final(w.A0, m->bf16, w.SA, pg.pout, pg.cnt_out, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H, W,
-                     C, m->Cout, s)) return 1;
+                     C, m->Cout, s, fstep)) return 1;
   }
   return 0;
 }
 
 // final_conv (model.py:111-115,151): GroupNorm + SiLU + 1x1 in one pass over the NHWC activation
 int launch_final(const float* u, int bf16, const float* stats, int pin, float cnt, const float* gamma, const float* beta,
-                 const float* wt, const float* bias, float* out, int B, int H, int W, int C, int Cout, hipStream_t s) {
+                 const float* wt, const float* bias, float* out, int B, int H, int W, int C, int Cout, hipStream_t s,
+                 const FinalStep* fs) {
   if (H * W % 64) return fail("final_conv: H*W must be a multiple of 64 (got %dx%d)", H, W);
+  FinalStep f;
+  memset(&f, 0, sizeof f);
+  if (fs) {
+    if (bf16 || C != 64) return fail("internal: the fused sampler update needs the fp32 C = 64 final_conv");
+    f = *fs;
+  }
   const size_t lds = (size_t)(3 * C + Cout * C) * sizeof(float);
   ProfScope ps(DM_K_FINAL, s, 2.0 * B * H * W * C * Cout, 4.0 * B * H * W * (C + Cout));
   const int slabs = (H * W / 64) >= 8 ? 8 : (H * W / 64);  // measured at 32x32, B=1024: 1 -> 96 us, 8 -> 62 us, 16 -> 85 us
@@ -1065,7 +1080,7 @@ int launch_final(const float* u, int bf16, const float* stats, int pin, float cn
                        gamma, beta, wt, bias, out, B, H * W, C, Cout, slabs);
   else
     hipLaunchKernelGGL(final_conv_kernel, grid, dim3(256), lds, s, u, stats, pin, cnt, gamma, beta, wt, bias, out, B, H * W, C,
-                       Cout, slabs);
+                       Cout, slabs, f);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1436,6 +1451,13 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
   // step index = *step_ptr + step_off (tables); `local` = index into the staged noise chunk
   auto one_step = [&](const int* step_ptr, int step_off, int local) -> int {
     if (!cfg) {
+      if (fuses_step(m, H, W)) {  // the update rides in final_conv's store: x is read and rewritten in place, element by element
+        FinalStep fsx;
+        memset(&fsx, 0, sizeof fsx);
+        fsx.x = xc; fsx.noise = noise ? w.noise : nullptr; fsx.coefs = w.coefs; fsx.step_ptr = step_ptr; fsx.xout = xc;
+        fsx.count = count; fsx.step_off = step_off; fsx.noise_idx = local;
+        return unet_body(m, packed, xc, w.eps, w.heads, 0, hstep, step_ptr, step_off, w, Bd, H, W, s, 0, &fsx);
+      }
       if (unet_body(m, packed, xc, w.eps, w.heads, 0, hstep, step_ptr, step_off, w, Bd, H, W, s)) return 1;
       return launch_step(xc, w.eps, noise ? w.noise : nullptr, local, w.coefs, step_ptr, step_off, nullptr, xc, count, 0, 0.f, s);
     }
@@ -1540,13 +1562,21 @@ int dm_unet_profile(dm_unet* m, const float* packed, float* x, const int64_t* t_
   Workspace w = carve(m, ws, B, H, W, 1);
   if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes", ws_bytes, w.bytes);
   hipStream_t s = (hipStream_t)stream;
+  if (fuses_step(m, H, W)) HIP_TRY(hipMemcpyAsync(w.coefs, coef_host, 8 * sizeof(float), hipMemcpyDefault, s));
   Prof prof;
   g_prof = &prof;
   int rc = 0;
   for (int r = 0; r < reps && !rc; ++r) {
     rc = launch_time_embed(m, packed, t_dev, 1, nullptr, w.temb, w.heads, s);
+    // the update goes out-of-place (into the workspace) so repeated profiling passes see the same input
+    if (!rc && fuses_step(m, H, W)) {  // as dm_sample runs it: the update inside final_conv
+      FinalStep fsx;
+      memset(&fsx, 0, sizeof fsx);
+      fsx.x = x; fsx.coefs = w.coefs; fsx.xout = w.xx; fsx.count = (size_t)B * m->Cin * H * W;
+      rc = unet_body(m, packed, x, w.eps, w.heads, 0, 0, nullptr, 0, w, B, H, W, s, 0, &fsx);
+      continue;
+    }
     if (!rc) rc = unet_body(m, packed, x, w.eps, w.heads, 0, 0, nullptr, 0, w, B, H, W, s);
-    // out-of-place (into the workspace) so repeated profiling passes see the same input
     if (!rc) rc = launch_step(x, w.eps, nullptr, 0, nullptr, nullptr, 0, coef_host, w.xx, (size_t)B * m->Cin * H * W, 0, 0.f, s);
   }
   g_prof = nullptr;

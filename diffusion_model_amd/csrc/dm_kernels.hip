@@ -1223,6 +1223,26 @@ __device__ __forceinline__ float dm_row16_sum(float v) {
   return v;
 }
 
+// The sampler update (schedulers.py:118-129 == sampler.py:121-132) folded into final_conv's store (C = 64, no guidance): the
+// thread that holds eps of an (image, channel, pixel) reads x (and the step's noise) there and writes the next x instead of eps -
+// one launch and an eps round trip less per step.  Same operations in the same order as sampler_step_kernel, no FMA
+// contraction: the result is bit-identical to the two-kernel form.
+struct FinalStep {
+  const float* x;        // null: plain final_conv (eps is written)
+  const float* noise;    // null or [*][count]; row noise_idx
+  const float* coefs;    // device table [n][8]
+  const int* step_ptr;
+  float* xout;           // may alias x
+  size_t count;          // elements of x
+  int step_off, noise_idx;
+};
+__device__ __forceinline__ float dm_step_math(float x, float e, float z, bool with_noise, float c0, float c1, float c2, float c3, float c4) {
+#pragma clang fp contract(off)
+  float o = c2 * ((x - c0 * e) / c1) + c3 * e;
+  if (with_noise) o = o + c4 * z;
+  return o;
+}
+
 // ------------------------------------------------------------------------------------------
 // final_conv (model.py:111-115,151): GroupNorm(8) -> SiLU -> Conv2d 1x1 (C -> Cout <= 4), NHWC in,
 // NCHW out.  One pass over the activation: bound by the HBM read of u3 (4*C bytes per pixel).
@@ -1231,7 +1251,7 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
                                                          int pin, float cnt_in, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                         int B, int HW, int C, int Cout, int slabs) {
+                                                         int B, int HW, int C, int Cout, int slabs, const FinalStep fs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_mean = smem;           // [C]
   float* s_scale = s_mean + C;    // [C]
@@ -1291,13 +1311,38 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
 #pragma unroll
     for (int co = 0; co < 4; ++co) wv[co] = (co < Cout) ? *reinterpret_cast<const float4*>(s_w + co * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float* ub = u + ((size_t)n * HW + pixb + p0) * C + c;
+    // Output side: the 16 sums of a thread's (pixel k, channel co) pairs end up in all 16 lanes of the pixel's row; lane q keeps
+    // the one of (k, co) = (q >> 2, q & 3) and stores it - one store per lane and slab.  The fused sampler update loads its x
+    // (and noise) element a slab ahead, behind the activation prefetch, so that nothing waits on it.
+    const int mk = q >> 2, mco = q & 3;
+    const bool mine = mco < Cout;
+    const size_t obase = ((size_t)n * Cout + (mine ? mco : 0)) * HW + pixb + p0 + 16 * mk;
+    const float mbias = bias[mine ? mco : 0];
+    float sc0 = 0.f, sc1 = 1.f, sc2 = 0.f, sc3 = 0.f, sc4 = 0.f;  // the step's coefficients (fused sampler update)
+    const float* nzr = nullptr;
+    const bool stepping = fs.x != nullptr;
+    if (stepping) {
+      const float* cc = fs.coefs + (size_t)((fs.step_ptr ? *fs.step_ptr : 0) + fs.step_off) * 8;
+      sc0 = cc[0]; sc1 = cc[1]; sc2 = cc[2]; sc3 = cc[3]; sc4 = cc[4];
+      if (fs.noise) nzr = fs.noise + (size_t)fs.noise_idx * fs.count;
+    }
     float4 cur[4], nxt[4];
+    float xcur = 0.f, zcur = 0.f, xnxt = 0.f, znxt = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) cur[k] = *reinterpret_cast<const float4*>(ub + (size_t)(16 * k) * C);
+    if (stepping && mine) {
+      xcur = fs.x[obase];
+      if (nzr) zcur = nzr[obase];
+    }
     for (int sl = 0; sl < slabs; ++sl) {
       const int sn = (sl + 1 < slabs) ? sl + 1 : sl;  // (clamped: the last prefetch re-reads valid data, unused)
 #pragma unroll
       for (int k = 0; k < 4; ++k) nxt[k] = *reinterpret_cast<const float4*>(ub + (size_t)(sn * 64 + 16 * k) * C);
+      if (stepping && mine) {
+        xnxt = fs.x[obase + sn * 64];
+        if (nzr) znxt = nzr[obase + sn * 64];
+      }
+      float keep = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float4 v = cur[k];
@@ -1309,13 +1354,20 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
         for (int co = 0; co < 4; ++co) {
           if (co < Cout) {
             float sm = v.x * wv[co].x + v.y * wv[co].y + v.z * wv[co].z + v.w * wv[co].w;
-            sm = dm_row16_sum(sm);  // the pixel's 16 lanes are one DPP row
-            if (q == 0) out[((size_t)n * Cout + co) * HW + pixb + sl * 64 + p0 + 16 * k] = sm + bias[co];
+            sm = dm_row16_sum(sm);  // the pixel's 16 lanes are one DPP row; every lane holds the same sum
+            keep = (q == k * 4 + co) ? sm : keep;
           }
         }
       }
+      if (mine) {
+        const float e = keep + mbias;
+        if (stepping) fs.xout[obase + sl * 64] = dm_step_math(xcur, e, zcur, nzr != nullptr, sc0, sc1, sc2, sc3, sc4);
+        else out[obase + sl * 64] = e;
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+      xcur = xnxt;
+      zcur = znxt;
     }
     return;
   }

@@ -135,3 +135,17 @@ def test_round2_entry_points_argument_checks_and_sizes():
     assert L.dm_attention(None, None, 1, 64, 64, None) != 0 and b"null" in L.dm_last_error()
     assert L.dm_final_conv(None, None, 1, 1.0, None, None, None, None, None, 1, 32, 32, 64, 1, None) != 0
     L.dm_unet_destroy(h)
+
+
+def test_uniform_beta_schedule_is_the_constant_schedule():
+    """schedulers.py:33: the reference's "uniform" branch calls `.to()` on a float and raises before any table exists
+    (SURVEY F10); what it spells - `torch.ones(T) * beta_end` - is a constant schedule, and that is what the drop-in builds.
+    Parity unpinned by the reference (it cannot run); the tables follow from the definition."""
+    s = d.DDPMScheduler(num_train_timesteps=50, beta_end=0.03, beta_schedule="uniform")
+    b = s.betas.cpu()
+    assert torch.equal(b, torch.ones(50) * 0.03)
+    acp = s.alphas_cumprod.cpu()
+    assert torch.allclose(acp, torch.cumprod(1 - b, 0)) and s.alphas_cumprod_prev.cpu()[0] == 1.0
+    assert s.posterior_variance.cpu()[0] == 0.0
+    with pytest.raises(ValueError, match="Unknown beta schedule"):
+        d.DDPMScheduler(beta_schedule="quadratic")

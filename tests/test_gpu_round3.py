@@ -87,3 +87,29 @@ def test_chunk_callback_errors_surface(model):
     rc = L.dm_sample_chunked(model._native(), _lib.ptr(model.packed_weights()), _lib.ptr(x), 2, 32, 32, _lib.ptr(ts_dev),
                              _lib.ptr(coefs), 10, None, 1, None, None, None, 1.0, _lib.ptr(ws), ws.numel(), 0, s.cuda_stream)
     assert rc != 0 and b"with_noise needs" in L.dm_last_error()
+
+
+@pytest.mark.parametrize("kind,eta,B", [("ddim", 0.0, 3), ("ancestral", 1.0, 5), ("ddim", 0.6, 64)])
+def test_update_folded_into_final_conv_equals_separate_step(model, kind, eta, B):
+    """The loop folds the sampler update into final_conv's store (fp32, C = 64, no guidance).  It must equal, bit for bit,
+    the reference's own form - model(x, t) then scheduler.step (sampler.py:69-79) - run call by call through dm_unet_forward
+    and dm_sampler_step."""
+    sched = d.DDPMScheduler()
+    if kind == "ddim":
+        smp = d.DDIMSampler(sched, num_inference_steps=50, eta=eta)
+    else:
+        smp = d.AncestralSampler(sched, num_inference_steps=1000, eta=eta)
+    ts = sched.timesteps = sched.timesteps[:12]
+    g = torch.Generator().manual_seed(31 + B)
+    x_T = torch.randn((B, 1, 32, 32), generator=g)
+    nz = torch.randn((len(ts), B, 1, 32, 32), generator=g) if eta > 0 else None
+    for use_graph in (True, False):
+        smp.use_graph = use_graph
+        got = smp.sample_from(model, x_T, nz)
+        x = x_T.to(DEV)
+        with torch.no_grad():
+            for i, t in enumerate(ts.tolist()):
+                eps = model(x, torch.tensor(t, device=DEV))
+                kw = {"noise": nz[i].to(DEV)} if eta > 0 else {}
+                x = smp.step(eps, t, x, **kw)
+        assert torch.equal(got, x), (kind, use_graph)
