@@ -5,6 +5,7 @@
 #include "dm_kernels.hip"
 #include "dm_kernels_bf16.hip"
 #include "dm_kernels_x6.hip"
+#include "dm_kernels_x6p.hip"
 #include "dm_kernels_init5.hip"
 #include "dm_kernels_generic.hip"
 #include "dm_kernels_lowres.hip"
@@ -128,7 +129,7 @@ unsigned long long* g_stamps = nullptr;  // diagnostic build: set through dm_deb
 #endif
 
 #ifndef DM_X6_DEFAULT
-#define DM_X6_DEFAULT 7
+#define DM_X6_DEFAULT 39
 #endif
 struct ConvCall {
   int kind;
@@ -145,7 +146,8 @@ struct ConvCall {
   const float* res; int no_silu;
   int bf16;  // activations and packed weights are bf16 (conv_bf16_kernel)
   int in_wrap;  // input images n >= in_wrap read image n - in_wrap (3x3 Winograd / bf16 3x3 kernel, one image per tile)
-  int x6;    // fp32 activations, weights packed as three bf16 split terms (conv_x6_kernel); kinds 0, 1/6, 2; 2: two-term form (opt-in)
+  int x6;    // fp32 activations, weights packed as three bf16 split terms (conv_x6_kernel); kinds 0, 1/6, 2; 2: two-term form (opt-in);
+             // 3: two fp16 terms (kinds 1/6, 2 behind a GroupNorm, one image per tile; the pack is pack_conv's kind 13 / 14)
   const float* init_x; const float* init_w; const float* init_b; int init_cin;  // folded init_conv
 };
 
@@ -193,12 +195,12 @@ int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
   return 0;
 }
 
-template <int MB, int KIND, bool SW, int NS = 3>
+template <int MB, int KIND, bool SW, int NS = 3, bool F16 = false>
 int launch_conv_x6_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_done[DM_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MB, KIND, SW, NS>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_kernel<MB, KIND, SW, NS, F16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
@@ -209,7 +211,23 @@ int launch_conv_x6_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : 4;
   const int cin = a.C1 + a.C2;
   ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 4.0 * (ipix * cin + opix * a.Cout) + 6.0 * taps * (UP ? 4 : 1) * cin * a.Cout);
-  hipLaunchKernelGGL((conv_x6_kernel<MB, KIND, SW, NS>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_x6_kernel<MB, KIND, SW, NS, F16>), grid, dim3(256), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+template <int MB, int NS, bool TF, bool F16 = false>
+int launch_conv_x6_down_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_done[DM_MAX_DEVICES] = {false};
+  const int dev = current_device();
+  if (!attr_done[dev]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_down_kernel<MB, NS, TF, F16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done[dev] = true;
+  }
+  const double opix = (double)a.B * a.Hb * a.Wb, ipix = (double)a.B * a.H * a.W;
+  ProfScope ps(DM_K_X6_DOWN, s, 2.0 * opix * a.Cout * 16.0 * a.C1, 4.0 * (ipix * a.C1 + opix * a.Cout) + 6.0 * 16.0 * a.C1 * a.Cout);
+  hipLaunchKernelGGL((conv_x6_down_kernel<MB, NS, TF, F16>), grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -257,11 +275,36 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   const size_t np = (size_t)g.ni * g.hth * g.htw;
   if (np * 8 > 3 * 256 * 8) return fail("conv (split-bf16): tile of %zu halo pixels is too large", np);
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
-  const int ns = c.x6 == 2 ? 2 : 3;  // split terms per operand
+  const int ns = c.x6 >= 2 ? 2 : 3;  // split terms per operand
+  const bool f16 = c.x6 == 3;        // two fp16 terms (inputs behind a GroupNorm)
+  if (f16 && (kind == 0 || !c.stats_in || g.ni != 1 || getenv("DM_DEBUG_NOSWAP")))
+    return fail("conv (fp16 split): stride-2 / transposed convolutions behind a GroupNorm, tiles of one image");
   size_t lds_f = (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (ns * np * 72 + 1) / 2 + 128;  // + reduction words behind the planes
   if (lds_f < epi_f) lds_f = epi_f;
   const size_t lds = lds_f * sizeof(float);
   if (lds > 160 * 1024) return fail("conv (split-bf16): tile needs %zu B of LDS (> 160 KiB)", lds);
+  // stride-2 conv, one image per tile: the kernel with its staging pipelined into the K loop (dm_kernels_x6p.hip)
+  static const bool x6_nopipe = getenv("DM_DEBUG_X6_NOPIPE") != nullptr;  // diagnostics only
+  const bool pipe = kind == 1 && g.ni == 1 && g.tw_log == 3 && g.hth == g.MT / 8 + 1 && g.htw == 9 && !c.c2 && !(c.stats_in && c.no_silu) && !x6_nopipe && !getenv("DM_DEBUG_NOSWAP");
+  if (pipe) {
+    const size_t lds_p = ((c.stats_in ? (size_t)3 * c.c1 : 0) + 64) * sizeof(float) + (size_t)2 * ns * np * 40 * 2;
+    if (lds_p > 80 * 1024) return fail("conv (split-bf16, stride 2): tile needs %zu B of LDS (> 80 KiB)", lds_p);
+    dim3 gridp((unsigned)(c.B * g.tiles_per_img), (unsigned)(c.cout / 64), 1u);
+    a.ntiles = (int)gridp.x;
+    const unsigned slots = 2u * cu_count(current_device());
+    const unsigned resident = slots / gridp.y ? slots / gridp.y : 1u;
+    if (gridp.x > resident) gridp.x = resident;
+    a.ngroups = c.B;
+    a.xcd_map = (gridp.x % 8 == 0 && gridp.y == 1 && c.B >= 64) ? 1 : 0;
+#ifdef DM_STAMPS
+    a.stamps = g_stamps;
+#endif
+#define DM_X6P(MB_) (f16 ? launch_conv_x6_down_t<MB_, 2, true, true>(a, gridp, lds_p, s) \
+                     : ns == 2 ? (c.stats_in ? launch_conv_x6_down_t<MB_, 2, true>(a, gridp, lds_p, s) : launch_conv_x6_down_t<MB_, 2, false>(a, gridp, lds_p, s)) \
+                               : (c.stats_in ? launch_conv_x6_down_t<MB_, 3, true>(a, gridp, lds_p, s) : launch_conv_x6_down_t<MB_, 3, false>(a, gridp, lds_p, s)))
+    return g.MT == 128 ? DM_X6P(2) : DM_X6P(1);
+#undef DM_X6P
+  }
   const int groups = (c.B + g.ni - 1) / g.ni;
   dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), (kind == 2 && !fused_up) ? 4u : 1u);
   a.ntiles = (int)grid.x;
@@ -282,6 +325,13 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   // one image per tile: swapped MFMA operands, stores straight from the registers (x6_epilogue_sw)
   static const bool x6_noswap = getenv("DM_DEBUG_NOSWAP") != nullptr;  // diagnostics only
   const bool sw = g.ni == 1 && !x6_noswap;
+#define DM_X6H(MB_, K_) launch_conv_x6_t<MB_, K_, true, 2, true>(a, grid, lds, s)
+  if (f16) {
+    if (kind == 1) return g.MT == 128 ? DM_X6H(2, 1) : DM_X6H(1, 1);
+    if (!fused_up) return g.MT == 128 ? DM_X6H(2, 2) : DM_X6H(1, 2);
+    return g.MT == 128 ? DM_X6H(2, 4) : DM_X6H(1, 4);
+  }
+#undef DM_X6H
 #define DM_X6(MB_, K_) (ns == 2 ? (sw ? launch_conv_x6_t<MB_, K_, true, 2>(a, grid, lds, s) : launch_conv_x6_t<MB_, K_, false, 2>(a, grid, lds, s)) \
                                : (sw ? launch_conv_x6_t<MB_, K_, true>(a, grid, lds, s) : launch_conv_x6_t<MB_, K_, false>(a, grid, lds, s)))
   if (kind == 0) return g.MT == 128 ? DM_X6(2, 0) : DM_X6(1, 0);
@@ -412,6 +462,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
 }
 
 size_t conv_packed_floats(int kind, int cin, int cout) {
+  if (kind == 13 || kind == 14) return (size_t)16 * cin * cout + 4;  // two fp16 planes + the float that undoes the weight scale
   if (kind >= 7 && kind <= 9) {  // split-bf16 form of kinds 0, 1, 2: three bf16 terms per weight
     const int taps = kind == 7 ? 9 : 16;
     return ((size_t)taps * cin * cout * 3 + 1) / 2;
@@ -433,6 +484,14 @@ int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream
     return 0;
   }
   if (cin % 16 || cout % 32) return fail("pack_conv: cin %% 16 / cout %% 32");
+  if (kind == 13 || kind == 14) {  // two-way fp16 split of kinds 1 / 2 (dm_kernels_x6.hip)
+    const size_t total = (size_t)16 * cin * cout;
+    hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1024), 0, s, w, total, out + total);
+    hipLaunchKernelGGL(pack_conv_weight_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind - 12, w, cin, cout,
+                       reinterpret_cast<bf16_t*>(out), total, out + total);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (kind >= 7 && kind <= 9) {
     const size_t total = (size_t)(kind == 7 ? 9 : 16) * cin * cout;
     hipLaunchKernelGGL(pack_conv_weight_x6_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind - 7, w, cin, cout,
@@ -457,7 +516,7 @@ int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream
 }  // namespace
 
 // ------------------------------------------------------------------ model container
-struct BlockOff { size_t tmw, tmb, c1, c1b, c2, c2b, tr, trb, g1, b1, g2, b2, c1w, c2w, c1x, c2x, trx; };  // c1w/c2w: Winograd form; *x: split-bf16 form
+struct BlockOff { size_t tmw, tmb, c1, c1b, c2, c2b, tr, trb, g1, b1, g2, b2, c1w, c2w, c1x, c2x, trx, trh; };  // c1w/c2w: Winograd form; *x: split-bf16 form; trh: two fp16 terms
 
 // A captured chunk of S sampling steps.  The nodes hold workspace addresses only (dm_sample stages
 // x, timesteps, coefficients, class embeddings and noise into the workspace), so the key is the
@@ -1010,8 +1069,12 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     // (phase, tap, channel slab, split term) does not depend on the tile, so the result is bit-identical either way - the
     // one place where the launch shape may follow the batch size without touching per-image results.
     if (!up && xt && kdn == 6 && !out_stats && (size_t)B * ((h / 2) * (ww / 2) / 128) <= cu_count(current_device())) kdn = 1;
-    base(up ? 2 : kdn, w.T2, C, nullptr, 0, xt ? o.trx : o.tr, o.trb, out, out_stats, h, ww);
-    c.x6 = xt ? xmode : 0;
+    // the stride-2 / transposed convolutions read SiLU(GroupNorm(.)): two fp16 terms and three MFMAs per product are as exact
+    // there as the three-way bf16 split; tiles of one image only (the swapped epilogue)
+    const ConvGeo gt = conv_geo(up ? 2 : kdn, h, ww, C);
+    const bool xh = xt && xmode == 1 && (x6 & 32) && gt.ni == 1;
+    base(up ? 2 : kdn, w.T2, C, nullptr, 0, xh ? o.trh : xt ? o.trx : o.tr, o.trb, out, out_stats, h, ww);
+    c.x6 = xh ? 3 : xt ? xmode : 0;
     with_tf(w.SB, kd, h, ww, o.g2, o.b2);
     return launch_conv(c, s);
   };
@@ -1201,7 +1264,7 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
   m->attn = attention ? 1 : 0;
   m->bf16 = 0;
   m->fast = fast ? 1 : 0;
-  m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 31 : DM_X6_DEFAULT;
+  m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 63 : DM_X6_DEFAULT;
   m->init5 = getenv("DM_INIT5") ? (atoi(getenv("DM_INIT5")) != 0) : 1;
   m->lowres = getenv("DM_LOWRES") ? (atoi(getenv("DM_LOWRES")) != 0) : 1;
   const int C = m->C, E = m->E;
@@ -1218,10 +1281,11 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
     b.tr = take(conv_packed_floats(up ? 2 : 1, C, C)); b.trb = take(C);
     b.c2 = take(conv_packed_floats(0, C, C)); b.c2b = take(C);
     b.g1 = take(C); b.b1 = take(C); b.g2 = take(C); b.b2 = take(C);
-    if (!fast) { b.c1w = b.c2w = b.c1x = b.c2x = b.trx = 0; continue; }  // (Winograd / split-bf16 forms: tuned kernels only)
+    if (!fast) { b.c1w = b.c2w = b.c1x = b.c2x = b.trx = b.trh = 0; continue; }  // (Winograd / split-bf16 forms: tuned kernels only)
     b.c1w = take(conv_packed_floats(5, up ? 2 * C : C, C)); b.c2w = take(conv_packed_floats(5, C, C));
     b.c1x = take(conv_packed_floats(7, up ? 2 * C : C, C)); b.c2x = take(conv_packed_floats(7, C, C));
     b.trx = take(conv_packed_floats(up ? 9 : 8, C, C));
+    b.trh = take(conv_packed_floats(up ? 14 : 13, C, C));
   }
   if (fast) {
     m->o_b0w = take(conv_packed_floats(5, C, C)); m->o_b3w = take(conv_packed_floats(5, C, C));
@@ -1294,7 +1358,7 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
     if (copy(b.tmw, p[i++], (size_t)C * E) || copy(b.tmb, p[i++], C)) return 1;
     if (xf && (pack_conv(5, p[i], up ? 2 * C : C, C, packed + b.c1w, s) || pack_conv(7, p[i], up ? 2 * C : C, C, packed + b.c1x, s))) return 1;
     if (pack_conv(0, p[i++], up ? 2 * C : C, C, packed + b.c1, s, m->bf16) || copy(b.c1b, p[i++], C)) return 1;
-    if (xf && pack_conv(up ? 9 : 8, p[i], C, C, packed + b.trx, s)) return 1;
+    if (xf && (pack_conv(up ? 9 : 8, p[i], C, C, packed + b.trx, s) || pack_conv(up ? 14 : 13, p[i], C, C, packed + b.trh, s))) return 1;
     if (pack_conv(up ? 2 : 1, p[i++], C, C, packed + b.tr, s, m->bf16) || copy(b.trb, p[i++], C)) return 1;
     if (xf && (pack_conv(5, p[i], C, C, packed + b.c2w, s) || pack_conv(7, p[i], C, C, packed + b.c2x, s))) return 1;
     if (pack_conv(0, p[i++], C, C, packed + b.c2, s, m->bf16) || copy(b.c2b, p[i++], C)) return 1;
@@ -1622,15 +1686,16 @@ size_t dm_conv_packed_floats(int kind, int cin, int cout) { return conv_packed_f
 
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev, void* stream) {
   if (!w_dev || !packed_dev) return fail("dm_pack_conv_weight: null argument");
-  if (kind < 0 || kind == 4 || kind > 12) return fail("unknown conv kind %d", kind);
+  if (kind < 0 || kind == 4 || kind > 14) return fail("unknown conv kind %d", kind);
   return pack_conv(kind, w_dev, cin, cout, packed_dev, (hipStream_t)stream);
 }
 
 // kinds 7, 8, 9: kinds 0, 1 (on 128-pixel tiles from 256 output pixels up, as the model does) and 2 in the split-bf16 form
-static int x6_base_kind(int kind, int H, int W) { return kind == 7 ? 0 : kind == 9 ? 2 : ((H / 2) * (W / 2) >= 256 ? 6 : 1); }
+// kinds 13, 14: kinds 8, 9 with the operands as two fp16 terms (inputs behind a GroupNorm only)
+static int x6_base_kind(int kind, int H, int W) { return kind == 7 ? 0 : (kind == 9 || kind == 14) ? 2 : ((H / 2) * (W / 2) >= 256 ? 6 : 1); }
 
 int dm_conv_stats_partials(int kind, int H, int W) {
-  if (kind < 0 || kind == 4 || kind > 9 || !is_pow2(H) || !is_pow2(W)) return 0;
+  if (kind < 0 || kind == 4 || (kind > 9 && kind != 13 && kind != 14) || !is_pow2(H) || !is_pow2(W)) return 0;
   if (kind >= 7) kind = x6_base_kind(kind, H, W);
   return conv_geo(kind, H, W, 64).pout;
 }
@@ -1658,6 +1723,7 @@ int dm_conv2d(int kind, const float* x1, int c1, const float* x2, int c2, const 
     return launch_gconv(kind - 10, x1, c1, c2 ? x2 : nullptr, c2, wp, bias, cout, y, B, H, W, (hipStream_t)stream);
   }
   if (kind >= 7 && kind <= 9) { c.x6 = 1; c.kind = x6_base_kind(kind, H, W); }
+  if (kind == 13 || kind == 14) { c.x6 = 3; c.kind = x6_base_kind(kind, H, W); }
   return launch_conv(c, (hipStream_t)stream);
 }
 

@@ -36,13 +36,37 @@ __device__ __forceinline__ void dm_split3(float a, float b, unsigned& s1, unsign
   s3 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, dm_bf2));
 }
 
+// Two-way fp16 split (the "f16x3" form, for inputs that went through GroupNorm): x = h1 + h2 with h1 = fp16(x) rounded TOWARD ZERO
+// (v_cvt_pkrtz_f16_f32: saturates instead of overflowing), h2 = fp16(x - h1) to nearest; the residual is exact, fp16 subnormals
+// are honoured by the conversions and by the MFMA (tools/diag/mfma_f16_denorm.hip), so |x - h1 - h2| <= max(2^-21 |x|, 3e-8).
+// Products h1 g1 + h1 g2 + h2 g1 (the dropped h2 g2 is <= 2^-20 of the product): three v_mfma_f32_32x32x16_f16 per fp32
+// product.  tools/diag/f16x3_sim.py: on layer-like data (activations of order 1) the result is as close to the fp64 dot
+// product as fp32-MFMA accumulation and the three-way bf16 split are; it loses relative accuracy only when ALL activations are
+// tiny (no normalisation in front) - which is why it serves the layers behind a GroupNorm only.
+typedef _Float16 dm_h2v __attribute__((ext_vector_type(2)));
+typedef _Float16 dm_h8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void dm_split_h2(float a, float b, unsigned& s1, unsigned& s2) {
+  dm_f2 v = {a, b};
+  const dm_h2v h = __builtin_bit_cast(dm_h2v, __builtin_amdgcn_cvt_pkrtz(a, b));
+  s1 = __builtin_bit_cast(unsigned, h);
+  v -= __builtin_convertvector(h, dm_f2);
+  s2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, dm_h2v));
+}
+// one 32x32x16 MFMA on eight 16-bit elements per lane: bf16 or fp16 operands
+template <bool F16>
+__device__ __forceinline__ f32x16 dm_mfma16(const uint4& a, const uint4& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(dm_h8v, a), __builtin_bit_cast(dm_h8v, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
 // Epilogue for the SWAPPED accumulator layout (weights as the MFMA's A operand, pixels as B): lane l holds pixel
 // (l & 31) of its 32-pixel block and the 16 channels  wn*32 + 8k + 4(l >> 5) + e  (k = r >> 2, e = r & 3), i.e. four
 // runs of four consecutive channels -> + bias, GroupNorm (mean, M2) partials, and 16-byte NHWC stores straight from the
 // registers: no LDS staging, no per-element address math.  One image per tile (ni == 1).  scr: 64 floats of LDS.
 template <int MB, int KIND>
 __device__ __forceinline__ void x6_epilogue_sw(const ConvArgs& p, f32x16 (&acc)[MB], float* scr, int par, int py, int px,
-                                               int img0, int tin, int y0, int x0, int wm, int wn, int lane, int h, int tid, int wave) {
+                                               int img0, int tin, int y0, int x0, int wm, int wn, int lane, int h, int tid, int wave,
+                                               float oscale = 1.f) {  // (fp16 form: the weights were packed times a power of two)
   constexpr bool UP = (KIND == 4 || KIND == 2);
   constexpr int MT = 64 * MB;
   const int OW = (KIND == 1) ? (p.W >> 1) : UP ? (p.W << 1) : p.W;
@@ -53,7 +77,8 @@ __device__ __forceinline__ void x6_epilogue_sw(const ConvArgs& p, f32x16 (&acc)[
     const float4 bv = *reinterpret_cast<const float4*>(p.bias + cb + 8 * k);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
-      acc[mb][4 * k] += bv.x; acc[mb][4 * k + 1] += bv.y; acc[mb][4 * k + 2] += bv.z; acc[mb][4 * k + 3] += bv.w;
+      acc[mb][4 * k] = fmaf(acc[mb][4 * k], oscale, bv.x); acc[mb][4 * k + 1] = fmaf(acc[mb][4 * k + 1], oscale, bv.y);
+      acc[mb][4 * k + 2] = fmaf(acc[mb][4 * k + 2], oscale, bv.z); acc[mb][4 * k + 3] = fmaf(acc[mb][4 * k + 3], oscale, bv.w);  // (oscale = 1: the plain sum)
     }
   }
   if (p.stats_out) {
@@ -127,8 +152,11 @@ __device__ __forceinline__ void x6_epilogue_sw(const ConvArgs& p, f32x16 (&acc)[
 
 // NS = 3: the fp32-equivalent form above.  NS = 2 (opt-in, DM_X6 bit 4): two bf16 terms per operand and THREE MFMAs per product
 // (a1 b1 + a1 b2 + a2 b1): operands carry 16-17 mantissa bits, about 7x the rounding error of an fp32 dot product.
-template <int MB, int KIND, bool SW = false, int NS = 3>
+// F16 (with NS = 2, SW): the two-way fp16 split above; the pack holds two fp16 planes and, behind them, the float 2^-k that undoes
+// the power-of-two scale of the packed weights.
+template <int MB, int KIND, bool SW = false, int NS = 3, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
+  static_assert(!F16 || (NS == 2 && SW), "the fp16 form has two planes and the swapped epilogue");
   constexpr int KC = 64;
   constexpr int MT = 64 * MB;
   constexpr int RSB = KC + 8;   // LDS row stride in bf16 (144 B: 16-B skew between pixels)
@@ -185,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
   const int cchunks = Cin / KC;
   const int nchunks = (KIND == 1) ? 4 * cchunks : cchunks;  // KIND 1: (phase, channel chunk)
   const bf16_t* wpk = reinterpret_cast<const bf16_t*>(p.wp);
+  const float oscale = F16 ? p.wp[NS * split_off / 2] : 1.f;  // the float behind the two fp16 planes
 
   // first-batch halo coordinates do not depend on the tile: (image << 16 | hy << 8 | hx), once per workgroup
   int hyx0[U];
@@ -295,10 +324,17 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
                 }
               }
               uint4 s1, s2, s3;
-              dm_split3(e[0], e[1], s1.x, s2.x, s3.x);
-              dm_split3(e[2], e[3], s1.y, s2.y, s3.y);
-              dm_split3(e[4], e[5], s1.z, s2.z, s3.z);
-              dm_split3(e[6], e[7], s1.w, s2.w, s3.w);
+              if constexpr (F16) {
+                dm_split_h2(e[0], e[1], s1.x, s2.x);
+                dm_split_h2(e[2], e[3], s1.y, s2.y);
+                dm_split_h2(e[4], e[5], s1.z, s2.z);
+                dm_split_h2(e[6], e[7], s1.w, s2.w);
+              } else {
+                dm_split3(e[0], e[1], s1.x, s2.x, s3.x);
+                dm_split3(e[2], e[3], s1.y, s2.y, s3.y);
+                dm_split3(e[4], e[5], s1.z, s2.z, s3.z);
+                dm_split3(e[6], e[7], s1.w, s2.w, s3.w);
+              }
               bf16_t* q = tile + pix * RSB + c8 * 8;
               *reinterpret_cast<uint4*>(q) = s1;
               *reinterpret_cast<uint4*>(q + PL) = s2;
@@ -330,6 +366,9 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
       }
+#ifdef DM_X6_FILLER
+      float fill0 = 0.5f, fill1 = 0.25f;
+#endif
       uint4 a0[NS][MB], a1[NS][MB];
       const bf16_t* ap[NS][MB];  // this lane's fragment address per plane at tap (0,0): per step only (tap offset) + immediate
 #pragma unroll
@@ -362,20 +401,19 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
           // cycles to issue, during which this wave feeds the matrix pipe nothing; one at a time they issue while
           // the MFMA in front of them executes (32 cycles).  Products in the order a1b3, a2b2, a1b2, a3b1, a2b1, a1b1
           // (small terms first); a weight term is reloaded for the next tap right after its last use.
-          const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, bq[j][0]);
-          const bf16x8_t b2 = __builtin_bit_cast(bf16x8_t, bq[j][1]);
-          const bf16x8_t b3 = __builtin_bit_cast(bf16x8_t, bq[j][NS - 1]);  // (NS = 2: unused)
+          const uint4 b1 = bq[j][0];
+          const uint4 b2 = bq[j][1];
+          const uint4 b3 = bq[j][NS - 1];  // (NS = 2: unused)
           __builtin_amdgcn_sched_barrier(0);
           constexpr int NTERM = (NS == 3) ? 6 : 3;  // NS = 2: a1b2, a2b1, a1b1
 #pragma unroll
           for (int t = 0; t < NTERM; ++t) {
             const int as = (NS == 3) ? ((t == 1 || t == 4) ? 1 : (t == 3) ? 2 : 0) : (t == 1 ? 1 : 0);
-            const bf16x8_t bv = (NS == 3) ? ((t == 0) ? b3 : (t == 1 || t == 2) ? b2 : b1) : (t == 0 ? b2 : b1);
+            const uint4 bv = (NS == 3) ? ((t == 0) ? b3 : (t == 1 || t == 2) ? b2 : b1) : (t == 0 ? b2 : b1);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-              const bf16x8_t av = __builtin_bit_cast(bf16x8_t, acur[as][mb]);
-              acc[mb] = SW ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[mb], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[mb], 0, 0, 0);
+              const uint4 av = acur[as][mb];
+              acc[mb] = SW ? dm_mfma16<F16>(bv, av, acc[mb]) : dm_mfma16<F16>(av, bv, acc[mb]);
               if (t < NS) anxt[t][mb] = *reinterpret_cast<const uint4*>(ap[t][mb] + noff);
               if (NS == 3) {
                 if (t == 3 && mb == 0) bq[j][2] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + 2 * split_off + j * jstride) + lane16);
@@ -384,6 +422,13 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
                 if (t == 1 && mb == MB - 1) bq[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + split_off + j * jstride) + lane16);
               }
               if (t == NTERM - 1 && mb == MB - 1) bq[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + j * jstride) + lane16);
+#ifdef DM_X6_FILLER  // timing experiment: vector instructions of the wave's own in the shadow of each MFMA
+#pragma unroll
+              for (int f = 0; f < DM_X6_FILLER; ++f) {
+                if (f & 1) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(fill1));
+                else asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(fill0));
+              }
+#endif
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -392,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
         if constexpr (KIND == 4) if ((tap & 3) == 3) {
           // one output parity is complete: registers -> HBM (the input tile stays in LDS for the next parity)
           par = tap >> 2; py = par >> 1; px = par & 1;
-          if constexpr (SW) x6_epilogue_sw<MB, 4>(p, acc, reinterpret_cast<float*>(tile + NS * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
+          if constexpr (SW) x6_epilogue_sw<MB, 4>(p, acc, reinterpret_cast<float*>(tile + NS * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, oscale);
           else conv_epilogue<MB, 4>(p, acc, reinterpret_cast<float*>(tile + NS * PL), nullptr, par, py, px, img0, tin, y0, x0,
                                     wm, wn, lane, h, tid, wave, bias_lane, true);
 #pragma unroll
@@ -406,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
     if constexpr (KIND != 4) {
       __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
       if constexpr (SW) {  // registers -> HBM; the reduction words sit behind the planes (no overlay, no barrier)
-        x6_epilogue_sw<MB, KIND>(p, acc, reinterpret_cast<float*>(tile + NS * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave);
+        x6_epilogue_sw<MB, KIND>(p, acc, reinterpret_cast<float*>(tile + NS * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, oscale);
       } else {
         __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
         conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, bias_lane, true);
@@ -448,4 +493,51 @@ __global__ void pack_conv_weight_x6_kernel(int kind, const float* __restrict__ w
   out[idx] = s1;
   out[total + idx] = s2;
   out[2 * total + idx] = f2bf(wv);
+}
+
+// Two-way fp16 split of a conv weight in the same B-fragment order, times 2^k with max |w| 2^k in [2^10, 2^11) so that both
+// terms of every weight of consequence are normal fp16 numbers; scale_inv (= 2^-k, written by weight_scale_kernel) sits
+// behind the two planes and is applied to the accumulators by the epilogue (exact).
+__global__ void weight_scale_kernel(const float* __restrict__ w, size_t n, float* __restrict__ scale_inv) {
+  __shared__ float red[1024];
+  float m = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    int e = 0;
+    if (red[0] > 0.f && red[0] < 3.0e38f) (void)frexpf(red[0], &e);  // max = f 2^e, f in [0.5, 1)
+    *scale_inv = ldexpf(1.f, e - 11);                               // weights are packed times 2^(11 - e)
+  }
+}
+__global__ void pack_conv_weight_h2_kernel(int kind, const float* __restrict__ w, int cin, int cout,
+                                           bf16_t* __restrict__ out, size_t total, const float* __restrict__ scale_inv) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int nty = kind == 0 ? 3 : kind == 1 ? 4 : 2;
+  const int nt = nty * nty;
+  const int ks = kind == 0 ? 3 : 4;
+  size_t r = idx;
+  const int e = r & 7; r >>= 3;
+  const int lane = r & 63; r >>= 6;
+  const int nb = r % (cout >> 5); r /= (cout >> 5);
+  const int c16 = r % (cin >> 4); r /= (cin >> 4);
+  const int tap = r % nt; r /= nt;
+  const int par = (int)r;
+  const int ty = tap / nty, tx = tap % nty;
+  int ky = ty, kx = tx;
+  if (kind == 2) { ky = 3 - (par >> 1) - 2 * ty; kx = 3 - (par & 1) - 2 * tx; }
+  const int co = nb * 32 + (lane & 31);
+  const int ci = c16 * 16 + 8 * (lane >> 5) + e;
+  const size_t src = (kind == 2) ? (((size_t)ci * cout + co) * ks + ky) * ks + kx
+                                 : (((size_t)co * cin + ci) * ks + ky) * ks + kx;
+  float wv = w[src] * (1.0f / *scale_inv);   // power of two: exact
+  const _Float16 h1 = (_Float16)wv;            // (weights: both terms to nearest)
+  wv -= (float)h1;
+  out[idx] = __builtin_bit_cast(bf16_t, h1);
+  out[total + idx] = __builtin_bit_cast(bf16_t, (_Float16)wv);
 }

@@ -1,7 +1,9 @@
 """Per-kernel parity (GPU) of the split-bf16 convolutions (conv_x6_kernel: fp32 operands as three bf16 terms, six bf16
 MFMAs per product, fp32 accumulation) through the C ABI against stock torch-CPU fp32 ops — to the SAME bounds as the
 fp32-MFMA kernels (tests/test_gpu_kernels.py): the arithmetic is fp32-equivalent, not a reduced-precision mode.
-kinds 7 / 8 / 9 = Conv2d 3x3 (model.py:41,45), Conv2d 4x4 stride 2 (model.py:46), ConvTranspose2d 4x4 stride 2 (model.py:43)."""
+kinds 7 / 8 / 9 = Conv2d 3x3 (model.py:41,45), Conv2d 4x4 stride 2 (model.py:46), ConvTranspose2d 4x4 stride 2 (model.py:43).
+kinds 13 / 14 = kinds 8 / 9 with the operands as TWO fp16 terms (three MFMAs per product), for inputs behind a GroupNorm - the
+model's default for its stride-2 / transposed convolutions; same bounds."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -17,8 +19,8 @@ def run_x6(kind, x1, x2, w, b, tf=None, want_stats=True):
     B, c1, H, W = x1.shape
     c2 = 0 if x2 is None else x2.shape[1]
     cin = c1 + c2
-    cout = w.shape[1] if kind == 9 else w.shape[0]
-    OH, OW = (H, W) if kind == 7 else (H // 2, W // 2) if kind == 8 else (2 * H, 2 * W)
+    cout = w.shape[1] if kind in (9, 14) else w.shape[0]
+    OH, OW = (H, W) if kind == 7 else (H // 2, W // 2) if kind in (8, 13) else (2 * H, 2 * W)
     wp = torch.empty(L.dm_conv_packed_floats(kind, cin, cout), device=DEV)
     wd = w.to(DEV).contiguous()
     _lib.check(L.dm_pack_conv_weight(kind, _lib.ptr(wd), cin, cout, _lib.ptr(wp), stream()))
@@ -40,7 +42,7 @@ def run_x6(kind, x1, x2, w, b, tf=None, want_stats=True):
 
 
 def ref_conv(kind, x, w, b):
-    return (F.conv2d(x, w, b, padding=1) if kind == 7 else F.conv2d(x, w, b, stride=2, padding=1) if kind == 8
+    return (F.conv2d(x, w, b, padding=1) if kind == 7 else F.conv2d(x, w, b, stride=2, padding=1) if kind in (8, 13)
             else F.conv_transpose2d(x, w, b, stride=2, padding=1))
 
 
@@ -91,7 +93,7 @@ def test_x6_conv_wide_and_concat(kind, B, H, cin, cout):
     check_stats(st, ref, B)
 
 
-@pytest.mark.parametrize("kind,H", [(7, 32), (8, 32), (9, 16), (8, 16), (9, 8), (7, 4)])
+@pytest.mark.parametrize("kind,H", [(7, 32), (8, 32), (9, 16), (8, 16), (9, 8), (7, 4), (13, 32), (14, 16), (13, 16), (14, 8), (13, 64), (14, 32)])
 def test_x6_conv_fused_groupnorm_silu_temb(kind, H):
     """Input transform SiLU(GroupNorm8(x)) + temb applied while staging (model.py:54-62), from producer partials."""
     torch.manual_seed(kind + H)
@@ -129,19 +131,59 @@ def test_x6_split_keeps_fp32_accuracy_on_badly_scaled_inputs():
 def test_x6_rows_of_a_large_batch_match_a_small_batch():
     """Persistent workgroups walk many tiles (XCD-aware order): rows of a B=600 launch == the same rows alone, bit for bit."""
     torch.manual_seed(9)
-    for kind, H in ((7, 16), (8, 32), (9, 16)):
+    for kind, H in ((7, 16), (8, 32), (9, 16), (13, 32), (14, 16)):
         k = 3 if kind == 7 else 4
         x = torch.randn(600, 64, H, H)
         w, b = torch.randn(64, 64, k, k) * 0.05, torch.randn(64)
-        y, st = run_x6(kind, x, None, w, b)
-        y2, st2 = run_x6(kind, x[592:].contiguous(), None, w, b)
+        tf = tf2 = None
+        if kind >= 13:  # the fp16 form reads SiLU(GroupNorm(.)): unit-variance partials
+            st0 = torch.zeros(600, 1, 8, 2)
+            st0[..., 1] = H * H * 8
+            mk = lambda sx: (sx.to(DEV), 1, float(H * H * 8), torch.ones(64, device=DEV), torch.zeros(64, device=DEV), torch.zeros(1, 64, device=DEV), 0)
+            tf, tf2 = mk(st0), mk(st0[592:].contiguous())
+        y, st = run_x6(kind, x, None, w, b, tf=tf)
+        y2, st2 = run_x6(kind, x[592:].contiguous(), None, w, b, tf=tf2)
         assert torch.equal(y[592:], y2) and torch.equal(st[592:], st2)
 
 
+def test_fp16_form_needs_a_groupnorm_in_front():
+    """kinds 13 / 14 without the fused GroupNorm transform are refused (un-normalised inputs could leave fp16's range)."""
+    L = _lib.lib()
+    x = torch.zeros(1, 16, 16, 64, device=DEV)
+    w = torch.zeros(64, 64, 4, 4, device=DEV)
+    wp = torch.empty(L.dm_conv_packed_floats(13, 64, 64), device=DEV)
+    _lib.check(L.dm_pack_conv_weight(13, _lib.ptr(w), 64, 64, _lib.ptr(wp), stream()))
+    y = torch.empty(1, 8, 8, 64, device=DEV)
+    rc = L.dm_conv2d(13, _lib.ptr(x), 64, None, 0, _lib.ptr(wp), _lib.ptr(torch.zeros(64, device=DEV)), 64, None, 0, 0.0, None, None,
+                     None, 0, _lib.ptr(y), None, 1, 16, 16, stream())
+    assert rc != 0 and b"GroupNorm" in L.dm_last_error()
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 30.0])
+def test_fp16_form_weight_scaling(scale):
+    """The packed weights are scaled by a power of two into fp16's normal range and un-scaled in the epilogue: tiny and large
+    weights give the same relative accuracy."""
+    torch.manual_seed(3)
+    B, H = 2, 32
+    h_raw = torch.randn(B, 64, H, H)
+    hg = h_raw.reshape(B, 8, -1)
+    mean = hg.mean(2)
+    st0 = torch.stack([mean, ((hg - mean[:, :, None]) ** 2).sum(2)], dim=-1).reshape(B, 1, 8, 2)
+    gamma, beta, temb = torch.rand(64) + 0.5, torch.randn(64) * 0.1, torch.randn(1, 64)
+    tf = (st0.to(DEV), 1, float(H * H * 8), gamma.to(DEV), beta.to(DEV), temb.to(DEV), 0)
+    hin = F.silu(F.group_norm(h_raw, 8, gamma, beta, eps=1e-5)) + temb[:, :, None, None]
+    for kind in (13, 14):
+        w, b = torch.randn(64, 64, 4, 4) * 0.05 * scale, torch.randn(64) * scale
+        y, _ = run_x6(kind, h_raw, None, w, b, tf=tf, want_stats=False)
+        ref = ref_conv(kind, hin.double(), w.double(), b.double())
+        assert (y.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 def test_x6_model_forward_matches_fp32_mfma_forward_and_oracle(monkeypatch):
-    """UNetMini.forward (model.py:120-151) with the 4x4 convolutions on the bf16 pipe (default, DM_X6=7) against the same
-    weights on the fp32-MFMA kernels only (DM_X6=0) and against the CPU oracle: the split-bf16 form moves eps by less
-    than the fp32 kernels' own distance from the oracle."""
+    """UNetMini.forward (model.py:120-151) with the 4x4 convolutions on the bf16 pipe (three-way bf16 split, DM_X6=7; the
+    default DM_X6=39 takes two fp16 terms for the layers behind a GroupNorm) against the same weights on the fp32-MFMA
+    kernels only (DM_X6=0) and against the CPU oracle: the split forms move eps by less than the fp32 kernels' own distance
+    from the oracle."""
     import diffusion_model_amd as d
     from oracle import unet_oracle as O
     d.set_seed(11)
@@ -152,15 +194,22 @@ def test_x6_model_forward_matches_fp32_mfma_forward_and_oracle(monkeypatch):
     m7 = d.UNetMini(image_size=32).eval()
     m7._native()
     m7.load_state_dict(m0.state_dict())
+    monkeypatch.setenv("DM_X6", "39")
+    m39 = d.UNetMini(image_size=32).eval()
+    m39._native()
+    m39.load_state_dict(m0.state_dict())
     x = torch.randn(24, 1, 32, 32)
     t = torch.tensor(437)
     with torch.no_grad():
         e0 = m0(x.to(DEV), t.to(DEV)).cpu()
         e7 = m7(x.to(DEV), t.to(DEV)).cpu()
+        e39 = m39(x.to(DEV), t.to(DEV)).cpu()
         ref = O.unet_forward({k: v.detach().cpu() for k, v in m0.state_dict().items()}, x, t)
-    assert not torch.equal(e0, e7)                       # (two different kernels did run)
-    assert (e0 - e7).abs().max().item() <= 2e-5
-    assert (e7 - ref).abs().max().item() <= 1e-4 and (e0 - ref).abs().max().item() <= 1e-4
+    assert not torch.equal(e0, e7) and not torch.equal(e7, e39)   # (different kernels did run)
+    assert (e0 - e7).abs().max().item() <= 2e-5 and (e0 - e39).abs().max().item() <= 2e-5
+    for e in (e0, e7, e39):
+        assert (e - ref).abs().max().item() <= 1e-4
+    print("eps error vs oracle: fp32-MFMA %.2e, bf16x6 %.2e, f16x3 %.2e" % tuple((e - ref).abs().max().item() for e in (e0, e7, e39)))
 
 
 @pytest.mark.parametrize("size,cin,ch", [(32, 1, 64), (16, 1, 64), (64, 3, 128)])

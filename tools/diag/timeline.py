@@ -15,6 +15,8 @@ x1 = torch.randn(B, H, H, 64, device=dev)
 ks = 3 if kind in (0, 5, 7) else 4
 OH = H // 2 if kind in (1, 6, 8) else 2 * H if kind in (2, 4, 9) else H
 w = torch.randn(64, 64, ks, ks, device=dev) * 0.05
+if os.environ.get("DM_TL_ZERO"):  # all-zero operands: how much of the time is switching power (clock) rather than issue slots?
+    x1.zero_(); w.zero_()
 wp = torch.empty(L.dm_conv_packed_floats(kind, 64, 64), device=dev)
 s = torch.cuda.current_stream().cuda_stream
 _lib.check(L.dm_pack_conv_weight(kind, _lib.ptr(w), 64, 64, _lib.ptr(wp), s))
