@@ -129,7 +129,7 @@ unsigned long long* g_stamps = nullptr;  // diagnostic build: set through dm_deb
 #endif
 
 #ifndef DM_X6_DEFAULT
-#define DM_X6_DEFAULT 39
+#define DM_X6_DEFAULT 231
 #endif
 struct ConvCall {
   int kind;
@@ -277,8 +277,8 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
   const int ns = c.x6 >= 2 ? 2 : 3;  // split terms per operand
   const bool f16 = c.x6 == 3;        // two fp16 terms (inputs behind a GroupNorm)
-  if (f16 && (kind == 0 || !c.stats_in || g.ni != 1 || getenv("DM_DEBUG_NOSWAP")))
-    return fail("conv (fp16 split): stride-2 / transposed convolutions behind a GroupNorm, tiles of one image");
+  if (f16 && (!c.stats_in || g.ni != 1 || getenv("DM_DEBUG_NOSWAP")))
+    return fail("conv (fp16 split): convolutions behind a GroupNorm, tiles of one image");
   size_t lds_f = (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (ns * np * 72 + 1) / 2 + 128;  // + reduction words behind the planes
   if (lds_f < epi_f) lds_f = epi_f;
   const size_t lds = lds_f * sizeof(float);
@@ -327,6 +327,7 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   const bool sw = g.ni == 1 && !x6_noswap;
 #define DM_X6H(MB_, K_) launch_conv_x6_t<MB_, K_, true, 2, true>(a, grid, lds, s)
   if (f16) {
+    if (kind == 0) return g.MT == 128 ? DM_X6H(2, 0) : DM_X6H(1, 0);
     if (kind == 1) return g.MT == 128 ? DM_X6H(2, 1) : DM_X6H(1, 1);
     if (!fused_up) return g.MT == 128 ? DM_X6H(2, 2) : DM_X6H(1, 2);
     return g.MT == 128 ? DM_X6H(2, 4) : DM_X6H(1, 4);
@@ -462,7 +463,7 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
 }
 
 size_t conv_packed_floats(int kind, int cin, int cout) {
-  if (kind == 13 || kind == 14) return (size_t)16 * cin * cout + 4;  // two fp16 planes + the float that undoes the weight scale
+  if (kind >= 13 && kind <= 15) return (size_t)(kind == 15 ? 9 : 16) * cin * cout + 4;  // two fp16 planes + the float that undoes the weight scale
   if (kind >= 7 && kind <= 9) {  // split-bf16 form of kinds 0, 1, 2: three bf16 terms per weight
     const int taps = kind == 7 ? 9 : 16;
     return ((size_t)taps * cin * cout * 3 + 1) / 2;
@@ -484,10 +485,10 @@ int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream
     return 0;
   }
   if (cin % 16 || cout % 32) return fail("pack_conv: cin %% 16 / cout %% 32");
-  if (kind == 13 || kind == 14) {  // two-way fp16 split of kinds 1 / 2 (dm_kernels_x6.hip)
-    const size_t total = (size_t)16 * cin * cout;
+  if (kind >= 13 && kind <= 15) {  // two-way fp16 split of kinds 1 / 2 / 0 (dm_kernels_x6.hip)
+    const size_t total = (size_t)(kind == 15 ? 9 : 16) * cin * cout;
     hipLaunchKernelGGL(weight_scale_kernel, dim3(1), dim3(1024), 0, s, w, total, out + total);
-    hipLaunchKernelGGL(pack_conv_weight_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind - 12, w, cin, cout,
+    hipLaunchKernelGGL(pack_conv_weight_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind == 15 ? 0 : kind - 12, w, cin, cout,
                        reinterpret_cast<bf16_t*>(out), total, out + total);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -516,7 +517,7 @@ int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream
 }  // namespace
 
 // ------------------------------------------------------------------ model container
-struct BlockOff { size_t tmw, tmb, c1, c1b, c2, c2b, tr, trb, g1, b1, g2, b2, c1w, c2w, c1x, c2x, trx, trh; };  // c1w/c2w: Winograd form; *x: split-bf16 form; trh: two fp16 terms
+struct BlockOff { size_t tmw, tmb, c1, c1b, c2, c2b, tr, trb, g1, b1, g2, b2, c1w, c2w, c1x, c2x, trx, trh, c2h, c1h; };  // c1w/c2w: Winograd form; *x: split-bf16 form; *h: two fp16 terms
 
 // A captured chunk of S sampling steps.  The nodes hold workspace addresses only (dm_sample stages
 // x, timesteps, coefficients, class embeddings and noise into the workspace), so the key is the
@@ -540,7 +541,7 @@ struct dm_unet {
   AttnOff att[2];
   size_t o_freqs, o_tm1w, o_tm1b, o_tm2w, o_tm2b, o_initw, o_initb;
   BlockOff blk[6];
-  size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb, o_b0w, o_b3w, o_b0x, o_b3x;
+  size_t o_b0, o_b0b, o_bg, o_bb, o_b3, o_b3b, o_fg, o_fb, o_fw, o_fwb, o_b0w, o_b3w, o_b0x, o_b3x, o_b0h, o_b3h;
   size_t o_i5w;        // init_conv composed with down1.conv1: nine weight sets (init5_kernel)
   int init5;           // 1: that composition replaces the two layers where the tile geometry allows (env DM_INIT5, default 1)
   int lowres;          // 1: the fused low-resolution kernel where it applies (env DM_LOWRES, default 1; read when the handle is created)
@@ -584,6 +585,12 @@ size_t max_stats_partials(int H, int W, int C) {
 // Do the tuned kernels (power-of-two tiles, Winograd / split-bf16 weight forms) cover HxW images of this model?
 // Everything else the reference accepts (H, W divisible by 8; C divisible by 8) runs on dm_kernels_generic.hip.
 bool tuned_geometry(const dm_unet* m, int H, int W) { return m->fast && is_pow2(H) && is_pow2(W) && H >= 8 && W >= 8; }
+
+// Does a block's conv2 at h x w (its input is behind a GroupNorm) run as a direct 3x3 convolution with the operands as two fp16
+// terms (conv_x6_kernel<.., 0, true, 2, true>)?  Where DM_X6 bit 6 asks for it and a tile holds one image; by geometry only.
+bool conv2_f16(const dm_unet* m, int h, int ww, bool shared_input) {
+  return !m->bf16 && (m->x6 & 64) && !(m->x6 & 16) && m->fast && !shared_input && h * ww >= 64 && is_pow2(h) && is_pow2(ww);
+}
 
 // Is the sampler update folded into final_conv's store (FinalStep)?  fp32, C = 64, tuned geometry, no guidance (the caller's part).
 bool fuses_step(const dm_unet* m, int H, int W) {
@@ -945,28 +952,33 @@ int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float
                   hipStream_t s) {
   LowresArgs a;
   memset(&a, 0, sizeof a);
-  auto layer = [&](size_t w, size_t bias, size_t gamma, size_t beta, bool norm, int temb_k) {
+  // wtot > 0: the pack is two fp16 planes of wtot elements with the float that undoes its power-of-two scale behind them
+  auto layer = [&](size_t w, size_t bias, size_t gamma, size_t beta, bool norm, int temb_k, size_t wtot) {
     LrLayer L;
     L.w = reinterpret_cast<const bf16_t*>(P + w); L.bias = P + bias;
     L.gamma = norm ? P + gamma : nullptr; L.beta = norm ? P + beta : nullptr; L.temb_k = temb_k;
+    L.wsc = wtot ? P + w + wtot : nullptr;
     return L;
   };
   const BlockOff &d2b = m->blk[1], &d3 = m->blk[2], &u1 = m->blk[3], &u2b = m->blk[4];
-  // fp32 path: the three-term split-bf16 packs (*x); bf16 path: the (hi, lo) pair packs - the same order, two terms
+  // fp32 path: two fp16 terms per operand (*h packs; DM_X6 bit 7) or the three-term split-bf16 packs (*x); bf16 path: the
+  // (hi, lo) pair packs - the same order, two terms
   const bool bf = m->bf16 != 0;
+  const bool hf = !bf && (m->x6 & 128);
+  const size_t C = (size_t)m->C, n3 = hf ? 9 * C * C : 0, n3c = 2 * n3, n4 = hf ? 16 * C * C : 0;
   a.t2 = t2; a.st2 = st2; a.pin2 = pin2; a.cnt2 = cnt2; a.g2 = P + d2b.g2; a.b2 = P + d2b.b2;
-  a.d2t = layer(bf ? d2b.tr : d2b.trx, d2b.trb, 0, 0, false, -1);
-  a.d3c1 = layer(bf ? d3.c1 : d3.c1x, d3.c1b, d3.g1, d3.b1, true, 2);
-  a.d3c2 = layer(bf ? d3.c2 : d3.c2x, d3.c2b, d3.g2, d3.b2, true, -1);
-  a.d3t = layer(bf ? d3.tr : d3.trx, d3.trb, 0, 0, false, -1);
-  a.b0 = layer(bf ? m->o_b0 : m->o_b0x, m->o_b0b, m->o_bg, m->o_bb, true, -1);
-  a.b3 = layer(bf ? m->o_b3 : m->o_b3x, m->o_b3b, 0, 0, false, -1);
-  a.u1c1 = layer(bf ? u1.c1 : u1.c1x, u1.c1b, u1.g1, u1.b1, true, 3);
-  a.u1c2 = layer(bf ? u1.c2 : u1.c2x, u1.c2b, u1.g2, u1.b2, true, -1);
-  a.u1t = layer(bf ? u1.tr : u1.trx, u1.trb, 0, 0, false, -1);
-  a.u2c1 = layer(bf ? u2b.c1 : u2b.c1x, u2b.c1b, u2b.g1, u2b.b1, true, 4);
-  a.u2c2 = layer(bf ? u2b.c2 : u2b.c2x, u2b.c2b, u2b.g2, u2b.b2, true, -1);
-  a.u2t = layer(bf ? u2b.tr : u2b.trx, u2b.trb, 0, 0, false, -1);
+  a.d2t = layer(bf ? d2b.tr : hf ? d2b.trh : d2b.trx, d2b.trb, 0, 0, false, -1, n4);
+  a.d3c1 = layer(bf ? d3.c1 : hf ? d3.c1h : d3.c1x, d3.c1b, d3.g1, d3.b1, true, 2, n3);
+  a.d3c2 = layer(bf ? d3.c2 : hf ? d3.c2h : d3.c2x, d3.c2b, d3.g2, d3.b2, true, -1, n3);
+  a.d3t = layer(bf ? d3.tr : hf ? d3.trh : d3.trx, d3.trb, 0, 0, false, -1, n4);
+  a.b0 = layer(bf ? m->o_b0 : hf ? m->o_b0h : m->o_b0x, m->o_b0b, m->o_bg, m->o_bb, true, -1, n3);
+  a.b3 = layer(bf ? m->o_b3 : hf ? m->o_b3h : m->o_b3x, m->o_b3b, 0, 0, false, -1, n3);
+  a.u1c1 = layer(bf ? u1.c1 : hf ? u1.c1h : u1.c1x, u1.c1b, u1.g1, u1.b1, true, 3, n3c);
+  a.u1c2 = layer(bf ? u1.c2 : hf ? u1.c2h : u1.c2x, u1.c2b, u1.g2, u1.b2, true, -1, n3);
+  a.u1t = layer(bf ? u1.tr : hf ? u1.trh : u1.trx, u1.trb, 0, 0, false, -1, n4);
+  a.u2c1 = layer(bf ? u2b.c1 : hf ? u2b.c1h : u2b.c1x, u2b.c1b, u2b.g1, u2b.b1, true, 4, n3c);
+  a.u2c2 = layer(bf ? u2b.c2 : hf ? u2b.c2h : u2b.c2x, u2b.c2b, u2b.g2, u2b.b2, true, -1, n3);
+  a.u2t = layer(bf ? u2b.tr : hf ? u2b.trh : u2b.trx, u2b.trb, 0, 0, false, -1, n4);
   a.heads = heads; a.heads_img_stride = heads_img_stride; a.heads_step_stride = heads_step_stride;
   a.step_ptr = step_ptr; a.step_off = step_off; a.d2 = d2; a.u2 = u2; a.B = B;
   a.taps = g_lowres_taps;
@@ -978,6 +990,7 @@ int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float
   if (!attr_done[dev]) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_fused_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
   unsigned grid = 2u * cu_count(dev);  // persistent: two workgroups per CU (60 KB of LDS each), images n, n + grid, ...
@@ -985,6 +998,7 @@ int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float
   // algorithmic work of the twelve layers: 25,231,360 multiply-adds per image
   ProfScope ps(DM_K_LOWRES, s, 2.0 * 25231360.0 * B, 4.0 * B * (2.0 * 16 * 16 * 64 + 2.0 * 8 * 8 * 64) + 6.0 * 12.6 * 64 * 64 * 9);
   if (bf) hipLaunchKernelGGL(lowres_fused_kernel<1>, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
+  else if (hf) hipLaunchKernelGGL(lowres_fused_kernel<2>, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
   else hipLaunchKernelGGL(lowres_fused_kernel<3>, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1054,8 +1068,12 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
       shared1 = shares_first_layers(m, B, h, ww, dup_half);
       if (launch_init5(m, P, x, w.T1, w.SA, shared1 ? dup_half : B, h, ww, s)) return 1;
     } else if (launch_conv(c, s)) return 1;
-    base(kd, w.T1, C, nullptr, 0, xs ? o.c2x : kd == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
-    c.x6 = xs ? xmode : 0;
+    // conv2 reads SiLU(GroupNorm(conv1)) + temb: two fp16 terms, three bf16-rate MFMAs per product, direct form - 3/16 of the
+    // fp32 MFMA time against Winograd's 4/9, and as exact; tiles of one image
+    const bool c2h = conv2_f16(m, h, ww, shared1);
+    const int k2 = c2h ? 0 : kd;
+    base(k2, w.T1, C, nullptr, 0, c2h ? o.c2h : xs ? o.c2x : k2 == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
+    c.x6 = c2h ? 3 : xs ? xmode : 0;  // (c2h implies h * w >= 64, where xs is off unless DM_X6 bit 3 is set)
     c.in_wrap = shared1 ? dup_half : 0;
     with_tf(w.SA, kd, h, ww, o.g1, o.b1);
     c.temb = heads + (size_t)k * C; c.temb_stride = heads_img_stride; c.temb_step_stride = heads_step_stride;
@@ -1075,7 +1093,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     const bool xh = xt && xmode == 1 && (x6 & 32) && gt.ni == 1;
     base(up ? 2 : kdn, w.T2, C, nullptr, 0, xh ? o.trh : xt ? o.trx : o.tr, o.trb, out, out_stats, h, ww);
     c.x6 = xh ? 3 : xt ? xmode : 0;
-    with_tf(w.SB, kd, h, ww, o.g2, o.b2);
+    with_tf(w.SB, k2, h, ww, o.g2, o.b2);
     return launch_conv(c, s);
   };
   if (block(0, w.A0, nullptr, H, W, false, w.D1, nullptr)) return 1;
@@ -1083,7 +1101,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     // everything at and below 8x8 pixels - down2.transform ... up2.transform, twelve layers - in ONE launch with the
     // activations in LDS (dm_kernels_lowres.hip); chosen by geometry only, so results do not depend on the batch
     if (block(1, w.D1, nullptr, H / 2, W / 2, false, nullptr, nullptr, true)) return 1;
-    const ConvGeo pg = conv_geo(k3(H / 2, W / 2), H / 2, W / 2, C);
+    const ConvGeo pg = conv_geo(conv2_f16(m, H / 2, W / 2, false) ? 0 : k3(H / 2, W / 2), H / 2, W / 2, C);
     if (launch_lowres(m, P, w.T2, w.SB, pg.pout, pg.cnt_out, heads, heads_img_stride, heads_step_stride, step_ptr, step_off, w.D2, w.U2, B, s))
       return 1;
     if (block(5, w.U2, w.D1, H / 2, W / 2, true, w.A0, w.SA)) return 1;
@@ -1264,7 +1282,7 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
   m->attn = attention ? 1 : 0;
   m->bf16 = 0;
   m->fast = fast ? 1 : 0;
-  m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 63 : DM_X6_DEFAULT;
+  m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 255 : DM_X6_DEFAULT;
   m->init5 = getenv("DM_INIT5") ? (atoi(getenv("DM_INIT5")) != 0) : 1;
   m->lowres = getenv("DM_LOWRES") ? (atoi(getenv("DM_LOWRES")) != 0) : 1;
   const int C = m->C, E = m->E;
@@ -1281,18 +1299,21 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
     b.tr = take(conv_packed_floats(up ? 2 : 1, C, C)); b.trb = take(C);
     b.c2 = take(conv_packed_floats(0, C, C)); b.c2b = take(C);
     b.g1 = take(C); b.b1 = take(C); b.g2 = take(C); b.b2 = take(C);
-    if (!fast) { b.c1w = b.c2w = b.c1x = b.c2x = b.trx = b.trh = 0; continue; }  // (Winograd / split-bf16 forms: tuned kernels only)
+    if (!fast) { b.c1w = b.c2w = b.c1x = b.c2x = b.trx = b.trh = b.c2h = b.c1h = 0; continue; }  // (Winograd / split-bf16 forms: tuned kernels only)
     b.c1w = take(conv_packed_floats(5, up ? 2 * C : C, C)); b.c2w = take(conv_packed_floats(5, C, C));
     b.c1x = take(conv_packed_floats(7, up ? 2 * C : C, C)); b.c2x = take(conv_packed_floats(7, C, C));
     b.trx = take(conv_packed_floats(up ? 9 : 8, C, C));
     b.trh = take(conv_packed_floats(up ? 14 : 13, C, C));
+    b.c2h = take(conv_packed_floats(15, C, C));
+    b.c1h = take(conv_packed_floats(15, up ? 2 * C : C, C));
   }
   if (fast) {
     m->o_b0w = take(conv_packed_floats(5, C, C)); m->o_b3w = take(conv_packed_floats(5, C, C));
     m->o_b0x = take(conv_packed_floats(7, C, C)); m->o_b3x = take(conv_packed_floats(7, C, C));
+    m->o_b0h = take(conv_packed_floats(15, C, C)); m->o_b3h = take(conv_packed_floats(15, C, C));
     m->o_i5w = take((size_t)9 * (25 * m->Cin + 1) * C);
   } else {
-    m->o_b0w = m->o_b3w = m->o_b0x = m->o_b3x = m->o_i5w = 0;
+    m->o_b0w = m->o_b3w = m->o_b0x = m->o_b3x = m->o_b0h = m->o_b3h = m->o_i5w = 0;
   }
   m->o_b0 = take(conv_packed_floats(0, C, C)); m->o_b0b = take(C);
   m->o_bg = take(C); m->o_bb = take(C);
@@ -1356,18 +1377,21 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
     const bool up = k >= 3;
     const BlockOff& b = m->blk[k];
     if (copy(b.tmw, p[i++], (size_t)C * E) || copy(b.tmb, p[i++], C)) return 1;
-    if (xf && (pack_conv(5, p[i], up ? 2 * C : C, C, packed + b.c1w, s) || pack_conv(7, p[i], up ? 2 * C : C, C, packed + b.c1x, s))) return 1;
+    if (xf && (pack_conv(5, p[i], up ? 2 * C : C, C, packed + b.c1w, s) || pack_conv(7, p[i], up ? 2 * C : C, C, packed + b.c1x, s) ||
+               pack_conv(15, p[i], up ? 2 * C : C, C, packed + b.c1h, s))) return 1;
     if (pack_conv(0, p[i++], up ? 2 * C : C, C, packed + b.c1, s, m->bf16) || copy(b.c1b, p[i++], C)) return 1;
     if (xf && (pack_conv(up ? 9 : 8, p[i], C, C, packed + b.trx, s) || pack_conv(up ? 14 : 13, p[i], C, C, packed + b.trh, s))) return 1;
     if (pack_conv(up ? 2 : 1, p[i++], C, C, packed + b.tr, s, m->bf16) || copy(b.trb, p[i++], C)) return 1;
-    if (xf && (pack_conv(5, p[i], C, C, packed + b.c2w, s) || pack_conv(7, p[i], C, C, packed + b.c2x, s))) return 1;
+    if (xf && (pack_conv(5, p[i], C, C, packed + b.c2w, s) || pack_conv(7, p[i], C, C, packed + b.c2x, s) ||
+               pack_conv(15, p[i], C, C, packed + b.c2h, s))) return 1;
     if (pack_conv(0, p[i++], C, C, packed + b.c2, s, m->bf16) || copy(b.c2b, p[i++], C)) return 1;
     if (copy(b.g1, p[i++], C) || copy(b.b1, p[i++], C) || copy(b.g2, p[i++], C) || copy(b.b2, p[i++], C)) return 1;
     return 0;
   };
   for (int k = 0; k < 3; ++k) if (do_block(k)) return 1;
   if (xf && (pack_conv(5, p[i], C, C, packed + m->o_b0w, s) || pack_conv(5, p[i + 4], C, C, packed + m->o_b3w, s) ||
-                   pack_conv(7, p[i], C, C, packed + m->o_b0x, s) || pack_conv(7, p[i + 4], C, C, packed + m->o_b3x, s))) return 1;
+                   pack_conv(7, p[i], C, C, packed + m->o_b0x, s) || pack_conv(7, p[i + 4], C, C, packed + m->o_b3x, s) ||
+                   pack_conv(15, p[i], C, C, packed + m->o_b0h, s) || pack_conv(15, p[i + 4], C, C, packed + m->o_b3h, s))) return 1;
   if (pack_conv(0, p[i++], C, C, packed + m->o_b0, s, m->bf16) || copy(m->o_b0b, p[i++], C) ||
       copy(m->o_bg, p[i++], C) || copy(m->o_bb, p[i++], C) ||
       pack_conv(0, p[i++], C, C, packed + m->o_b3, s, m->bf16) || copy(m->o_b3b, p[i++], C)) return 1;
@@ -1686,16 +1710,16 @@ size_t dm_conv_packed_floats(int kind, int cin, int cout) { return conv_packed_f
 
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev, void* stream) {
   if (!w_dev || !packed_dev) return fail("dm_pack_conv_weight: null argument");
-  if (kind < 0 || kind == 4 || kind > 14) return fail("unknown conv kind %d", kind);
+  if (kind < 0 || kind == 4 || kind > 15) return fail("unknown conv kind %d", kind);
   return pack_conv(kind, w_dev, cin, cout, packed_dev, (hipStream_t)stream);
 }
 
 // kinds 7, 8, 9: kinds 0, 1 (on 128-pixel tiles from 256 output pixels up, as the model does) and 2 in the split-bf16 form
 // kinds 13, 14: kinds 8, 9 with the operands as two fp16 terms (inputs behind a GroupNorm only)
-static int x6_base_kind(int kind, int H, int W) { return kind == 7 ? 0 : (kind == 9 || kind == 14) ? 2 : ((H / 2) * (W / 2) >= 256 ? 6 : 1); }
+static int x6_base_kind(int kind, int H, int W) { return (kind == 7 || kind == 15) ? 0 : (kind == 9 || kind == 14) ? 2 : ((H / 2) * (W / 2) >= 256 ? 6 : 1); }
 
 int dm_conv_stats_partials(int kind, int H, int W) {
-  if (kind < 0 || kind == 4 || (kind > 9 && kind != 13 && kind != 14) || !is_pow2(H) || !is_pow2(W)) return 0;
+  if (kind < 0 || kind == 4 || (kind > 9 && kind < 13) || kind > 15 || !is_pow2(H) || !is_pow2(W)) return 0;
   if (kind >= 7) kind = x6_base_kind(kind, H, W);
   return conv_geo(kind, H, W, 64).pout;
 }
@@ -1723,7 +1747,7 @@ int dm_conv2d(int kind, const float* x1, int c1, const float* x2, int c2, const 
     return launch_gconv(kind - 10, x1, c1, c2 ? x2 : nullptr, c2, wp, bias, cout, y, B, H, W, (hipStream_t)stream);
   }
   if (kind >= 7 && kind <= 9) { c.x6 = 1; c.kind = x6_base_kind(kind, H, W); }
-  if (kind == 13 || kind == 14) { c.x6 = 3; c.kind = x6_base_kind(kind, H, W); }
+  if (kind >= 13 && kind <= 15) { c.x6 = 3; c.kind = x6_base_kind(kind, H, W); }
   return launch_conv(c, (hipStream_t)stream);
 }
 

@@ -17,6 +17,12 @@
 // one pixel and four runs of four consecutive channels.  Workgroup = 4 waves: at 8x8 as 2 (pixel halves) x 2 (channel
 // halves); at 4x4 (16 pixels: half a 32-row block) the pixel-half index splits K instead and the two partial sums meet
 // through LDS, or - transposed conv 4x4 -> 8x8 - it splits the four output parities.
+// NA = 2 (the fp32 path's default): every operand as TWO fp16 terms, three v_mfma_f32_32x32x16_f16 per product (dm_split_h2,
+// dm_kernels_x6.hip: as exact as the three-way bf16 split for operands of order 1).  Layer outputs that went through a
+// GroupNorm are of order 1 by construction; the five tensors a consumer reads RAW (down2's, down3's, the bottleneck's, up1's
+// outputs and down2's copy from global memory) are scaled by a power of two taken from the tensor's largest magnitude
+// (whole-image maximum over the workgroup, exact) before they are split, and the consumer's accumulators are scaled back
+// together with the weight pack's own power of two - so the form holds for activations of any magnitude.
 // NA = 1 is the bf16 path's form (BASELINE configs[3]): ONE bf16 activation plane, the weights as (hi, lo) bf16 pairs - the
 // first two terms of the same packing -, two MFMAs per product; input as IEEE half, output as bf16 like the layer kernels.
 // Chosen by the layer geometry only (C = 64, 32x32 images, fp32, no attention), never by the batch size: per-image results
@@ -30,6 +36,7 @@ struct LrLayer {
   const float* gamma;  // GroupNorm applied to this layer's OUTPUT (null: the consumer reads it raw)
   const float* beta;
   int temb_k;          // time-embedding head added after that GroupNorm + SiLU (block index 0..5), -1: none
+  const float* wsc;    // NA = 2: the float 2^-k behind the two fp16 planes of the pack (pack_conv kinds 13-15); else null
 };
 
 struct LowresArgs {
@@ -69,7 +76,8 @@ constexpr int X8_BYTES = 16384;          // 8x8 level: K-split exchange area = t
 // parameters / time-embedding rows, loaded once per workgroup (time embedding: per image) so that no epilogue waits on L2
 constexpr int SM_SCALE = 0, SM_SHIFT = 64, SM_RED = 128, SM_BIAS = 192;   // bias [12][64]
 constexpr int SM_GAMMA = SM_BIAS + 12 * 64, SM_BETA = SM_GAMMA + 7 * 64, SM_TEMB = SM_BETA + 7 * 64;  // [7][64], [7][64], [3][64]
-constexpr int SM_FLOATS = SM_TEMB + 3 * 64;
+constexpr int SM_WSC = SM_TEMB + 3 * 64;   // [12] weight-pack scales (NA = 2), padded to 16
+constexpr int SM_FLOATS = SM_WSC + 16;
 constexpr int LDS_BYTES = P_BYTES + X8_BYTES + SM_FLOATS * 4;
 constexpr size_t JS = 1024;        // weight elements per (16 input channels, 64 output channels)
 
@@ -162,6 +170,16 @@ __device__ __forceinline__ void krun(f32x16& acc, WFrag& f, const bf16_t* ap, in
         __builtin_amdgcn_sched_barrier(0);
         LR_MFMA(b1, a1, acc, j & 1);
         f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+      } else if constexpr (NA == 2) {  // two fp16 terms each: h1 g2, h2 g1, h1 g1
+        acc = dm_mfma16<true>(f.q[j][1], a[c][0], acc);
+        a[nx][0] = *reinterpret_cast<const uint4*>(an);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = dm_mfma16<true>(f.q[j][0], a[c][1], acc);
+        a[nx][1] = *reinterpret_cast<const uint4*>(an + pl);
+        f.q[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + w.so + (size_t)j * JS) + lane16);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = dm_mfma16<true>(f.q[j][0], a[c][0], acc);
+        f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
       } else {  // bf16 activations x (hi, lo) weights: a1 lo, then a1 hi
         LR_MFMA(b2, a1, acc, j & 1);
         a[nx][0] = *reinterpret_cast<const uint4*>(an);
@@ -247,6 +265,24 @@ __device__ __forceinline__ void krun2(f32x16& acc0, f32x16& acc1, WFrag& f, cons
         LR_MFMA(b1, p1, acc0, j & 1);
         LR_MFMA(b1, q1, acc1, j & 1);
         f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+      } else if constexpr (NA == 2) {  // two fp16 terms each: h1 g2, h2 g1, h1 g1; block 0 then block 1
+        acc0 = dm_mfma16<true>(f.q[j][1], a[c][0][0], acc0);
+        a[nx][0][0] = *reinterpret_cast<const uint4*>(an0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = dm_mfma16<true>(f.q[j][1], a[c][1][0], acc1);
+        a[nx][1][0] = *reinterpret_cast<const uint4*>(an1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = dm_mfma16<true>(f.q[j][0], a[c][0][1], acc0);
+        a[nx][0][1] = *reinterpret_cast<const uint4*>(an0 + pl);
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = dm_mfma16<true>(f.q[j][0], a[c][1][1], acc1);
+        a[nx][1][1] = *reinterpret_cast<const uint4*>(an1 + pl);
+        f.q[j][1] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + w.so + (size_t)j * JS) + lane16);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = dm_mfma16<true>(f.q[j][0], a[c][0][0], acc0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = dm_mfma16<true>(f.q[j][0], a[c][1][0], acc1);
+        f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
       } else {  // bf16 activations x (hi, lo) weights
         LR_MFMA(b2, p1, acc0, j & 1);
         a[nx][0][0] = *reinterpret_cast<const uint4*>(an0);
@@ -301,6 +337,42 @@ __device__ __forceinline__ void add_bias(f32x16& acc, const float* bias, int cb)
     const float4 bv = *reinterpret_cast<const float4*>(bias + cb + 8 * k);
     acc[4 * k] += bv.x; acc[4 * k + 1] += bv.y; acc[4 * k + 2] += bv.z; acc[4 * k + 3] += bv.w;
   }
+}
+
+// acc = acc * osc + bias (osc = 1: the plain sum, bit for bit)
+__device__ __forceinline__ void scale_bias(f32x16& acc, float osc, const float* bias, int cb) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 bv = *reinterpret_cast<const float4*>(bias + cb + 8 * k);
+    acc[4 * k] = fmaf(acc[4 * k], osc, bv.x); acc[4 * k + 1] = fmaf(acc[4 * k + 1], osc, bv.y);
+    acc[4 * k + 2] = fmaf(acc[4 * k + 2], osc, bv.z); acc[4 * k + 3] = fmaf(acc[4 * k + 3], osc, bv.w);
+  }
+}
+
+// largest magnitude of the lane's 16 values
+__device__ __forceinline__ float lane_amax(const f32x16& acc) {
+  float m = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(acc[r]));
+  return m;
+}
+// Power-of-two scale of a tensor a consumer reads raw (NA = 2): the workgroup-wide maximum of `m` (0 from lanes / waves that
+// hold nothing) through 4 LDS words and ONE barrier - every wave must call it -, then s = 2^k with max * s in [2^10, 2^11)
+// (exponent clamped: zeros and denormal-sized tensors keep s <= 2^117).  Returns s; inv = 1 / s.
+__device__ __forceinline__ float wg_scale(float m, float* red4, int wave, float& inv) {
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 8, 64));
+  m = fmaxf(m, __shfl_xor(m, 4, 64));
+  m = fmaxf(m, __shfl_xor(m, 2, 64));
+  m = fmaxf(m, __shfl_xor(m, 1, 64));
+  if ((threadIdx.x & 63) == 0) red4[wave] = m;
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(red4[0], red4[1]), fmaxf(red4[2], red4[3]));
+  int eb = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+  eb = min(max(eb, 20), 240);
+  inv = __uint_as_float((unsigned)(eb - 10) << 23);
+  return __uint_as_float((unsigned)(264 - eb) << 23);
 }
 
 // sum over the 64 lanes of a wave, result in every lane
@@ -365,10 +437,18 @@ __device__ __forceinline__ void gn_silu_regs(f32x16& acc, bool valid, float inv_
 
 // the lane's 16 values -> three bf16 planes at pixel index pix of a plane buffer (plane stride pl)
 template <int NA>
-__device__ __forceinline__ void put_planes(const f32x16& acc, bf16_t* buf, int pl, int pix, int cb) {
+__device__ __forceinline__ void put_planes(const f32x16& acc, bf16_t* buf, int pl, int pix, int cb, float sc = 1.f) {
   bf16_t* q = buf + pix * RSB + cb;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
+    if constexpr (NA == 2) {  // two fp16 planes of the values times sc (a power of two)
+      uint2 s1, s2;
+      dm_split_h2(acc[4 * k] * sc, acc[4 * k + 1] * sc, s1.x, s2.x);
+      dm_split_h2(acc[4 * k + 2] * sc, acc[4 * k + 3] * sc, s1.y, s2.y);
+      *reinterpret_cast<uint2*>(q + 8 * k) = s1;
+      *reinterpret_cast<uint2*>(q + 8 * k + pl) = s2;
+      continue;
+    }
     if constexpr (NA == 1) {  // one plane: round to nearest even
       uint2 s1;
       s1.x = (unsigned)f2bf(acc[4 * k]) | ((unsigned)f2bf(acc[4 * k + 1]) << 16);
@@ -387,7 +467,17 @@ __device__ __forceinline__ void put_planes(const f32x16& acc, bf16_t* buf, int p
 
 // eight fp32 values (two float4) -> three bf16 planes, 16 bytes each, at q
 template <int NA>
-__device__ __forceinline__ void put_planes8(float4 w0, float4 w1, bf16_t* q, int pl) {
+__device__ __forceinline__ void put_planes8(float4 w0, float4 w1, bf16_t* q, int pl, float sc = 1.f) {
+  if constexpr (NA == 2) {
+    uint4 s1, s2;
+    dm_split_h2(w0.x * sc, w0.y * sc, s1.x, s2.x);
+    dm_split_h2(w0.z * sc, w0.w * sc, s1.y, s2.y);
+    dm_split_h2(w1.x * sc, w1.y * sc, s1.z, s2.z);
+    dm_split_h2(w1.z * sc, w1.w * sc, s1.w, s2.w);
+    *reinterpret_cast<uint4*>(q) = s1;
+    *reinterpret_cast<uint4*>(q + pl) = s2;
+    return;
+  }
   if constexpr (NA == 1) {
     uint4 s1;
     s1.x = (unsigned)f2bf(w0.x) | ((unsigned)f2bf(w0.y) << 16); s1.y = (unsigned)f2bf(w0.z) | ((unsigned)f2bf(w0.w) << 16);
@@ -485,7 +575,16 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       }
     }
   }
+  if (tid < 12) {
+    const LrLayer* Ls[12] = {&p.d2t, &p.d3c1, &p.d3c2, &p.d3t, &p.b0, &p.b3, &p.u1c1, &p.u1c2, &p.u1t, &p.u2c1, &p.u2c2, &p.u2t};
+    float v = 1.f;
+#pragma unroll
+    for (int l = 0; l < 12; ++l) if (l == tid && NA == 2) v = *Ls[l]->wsc;
+    sm[SM_WSC + tid] = v;   // (1 where the pack carries no scale)
+  }
   const float* bias_t = sm + SM_BIAS;
+  const float* wsc = sm + SM_WSC;
+  float* red4 = sm + SM_RED + 32;   // wg_scale's exchange words
 
   // weight streams (wave-uniform): {fragment base, tap stride, split stride}
   // (8x8 layers: the wave pair index wm is the K half kh - channel slabs 2kh, 2kh+1 -, see krun2)
@@ -590,10 +689,12 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     }
     kload<NA, 2>(wf, w_d3c1, 0, lane16);
     kx_exchange(acc, acc1, wm, wave, lane, X8);  // (its barrier: every wave is done reading the phase planes)
-    add_bias(acc, bias_t + 0 * 64, cb);
+    scale_bias(acc, wsc[0], bias_t + 0 * 64, cb);
     put_f32(acc, p.d2 + ((size_t)n * 64 + m8) * 64 + cb);  // down2's output, raw: skip input of up2.conv1, read back by this workgroup
     zero_ring<NA, 10>(P, PL);
-    put_planes<NA>(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);  // ... and, as planes, the input of down3.conv1
+    float s_d2 = 1.f, i_d2 = 1.f;   // power-of-two scale of down2's output as planes (NA = 2), and its inverse
+    if constexpr (NA == 2) s_d2 = wg_scale(lane_amax(acc), red4, wave, i_d2);
+    put_planes<NA>(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb, s_d2);  // ... and, as planes, the input of down3.conv1
 
     LR_STAMP(1);
     // ================= B, C: down3.conv1, down3.conv2, Conv2d 3x3 p1 at 8x8 (model.py:54-62) =================
@@ -608,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     LR_STAMP(14);
     kload<NA, 2>(wf, w_d3c2, 0, lane16);
     kx_exchange(acc, acc1, wm, wave, lane, X8);
-    add_bias(acc, bias_t + 1 * 64, cb);
+    scale_bias(acc, wsc[1] * i_d2, bias_t + 1 * 64, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 0 * 64, sm + SM_BETA + 0 * 64, sm + SM_TEMB + 0 * 64, cb, red, wave, wn);
     LR_STAMP(15);
     // (the two barriers inside: every wave is past its K loop, P may be rewritten; the halo ring stays zero)
@@ -620,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     krun2<NA, 2>(acc, acc1, wf, a8a, a8b, PL, w_d3c2, lane16, 9, tap3_10);
     kload<NA>(wf, w_d3t, wt_phase(wm_s, 0, 0, 0), lane16);
     kx_exchange(acc, acc1, wm, wave, lane, X8);
-    add_bias(acc, bias_t + 2 * 64, cb);
+    scale_bias(acc, wsc[2], bias_t + 2 * 64, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 1 * 64, sm + SM_BETA + 1 * 64, nullptr, cb, red, wave, wn);
     // output in the four-phase layout of the stride-2 conv: input pixel (y, x) = (2Y - a, 2X - b) -> plane (a, b) pixel (Y, X) of 5x5
     {
@@ -657,8 +758,12 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     if (!wm) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += X[(wn * 16 + r) * 64 + lane];
-      add_bias(acc, bias_t + 3 * 64, cb);
-      if (v4) put_planes<NA>(acc, D3p, PL4, pix6, cb);  // down3's output, raw: input of bottleneck.0 and skip input of up1.conv1
+      scale_bias(acc, wsc[3], bias_t + 3 * 64, cb);
+    }
+    float s_d3 = 1.f, i_d3 = 1.f;   // scale of down3's output as planes
+    if constexpr (NA == 2) s_d3 = wg_scale((!wm && v4) ? lane_amax(acc) : 0.f, red4, wave, i_d3);
+    if (!wm) {
+      if (v4) put_planes<NA>(acc, D3p, PL4, pix6, cb, s_d3);  // down3's output, raw: input of bottleneck.0 and skip input of up1.conv1
       if (p.taps && v4) put_f32(acc, p.taps + (size_t)n * 6144 + m4 * 64 + cb);
     }
 
@@ -668,35 +773,44 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     auto tap3_6 = [&](int t, int& ao, int& wt) { const int ty = t / 3; ao = (ty * 6 + t - 3 * ty) * RSB; wt = t; };
     // in1 != null: K = [in0, in1] channels, one input per wave pair.  After the K loop the next layer's first weight
     // fragments are requested (wsn, wtn0), then the partial sums meet and the wm = 0 pair finishes the layer.
+    // isc0 / isc1: inverse input scales of in0 / in1 (NA = 2; 1 otherwise).  The output is GroupNorm'ed (ni >= 0: order 1, no
+    // scale) or raw (then it gets its own power-of-two scale, returned through s_out / i_out).
     auto conv4 = [&](const bf16_t* in0, const bf16_t* in1, const WS& ws, int li, int ni, const float* temb, bf16_t* out, int tap_off,
-                     const WS& wsn, int wtn0) {
+                     const WS& wsn, int wtn0, float isc0, float isc1, float& s_out, float& i_out) {
       __syncthreads();  // the input planes are complete; the exchange area is free
       zero_acc(acc);
       const int a4 = (y4 * 6 + x4) * RSB + 8 * h;
       if (in1) krun<NA>(acc, wf, (wm_s ? in1 : in0) + a4, PL4, ws, lane16, 9, tap3_6);
       else krun<NA>(acc, wf, in0 + a4, PL4, ws, lane16, wm_s ? 4 : 5, [&](int t, int& ao, int& wt) { tap3_6(t + 5 * wm_s, ao, wt); });
       kload<NA>(wf, wsn, wtn0, lane16);
+      // each K half back to the true scale (weights' and its input's powers of two; 1 x 1 outside NA = 2), then the halves meet
+      const float osc = wsc[li] * ((in1 && wm_s) ? isc1 : isc0);
       if (wm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) X[(wn * 16 + r) * 64 + lane] = acc[r];
+        for (int r = 0; r < 16; ++r) X[(wn * 16 + r) * 64 + lane] = acc[r] * osc;
       }
       __syncthreads();
       if (!wm) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += X[(wn * 16 + r) * 64 + lane];
-        add_bias(acc, bias_t + li * 64, cb);
+        for (int r = 0; r < 16; ++r) acc[r] = fmaf(acc[r], osc, X[(wn * 16 + r) * 64 + lane]);
+        scale_bias(acc, 1.f, bias_t + li * 64, cb);
         if (ni >= 0) gn_silu_regs<1>(acc, v4, 1.0f / 128.0f, sm + SM_GAMMA + ni * 64, sm + SM_BETA + ni * 64, temb, cb, red, wave, wn);
-        if (v4) put_planes<NA>(acc, out, PL4, pix6, cb);
+      }
+      s_out = 1.f; i_out = 1.f;
+      if constexpr (NA == 2) if (ni < 0) s_out = wg_scale((!wm && v4) ? lane_amax(acc) : 0.f, red4, wave, i_out);
+      if (!wm) {
+        if (v4) put_planes<NA>(acc, out, PL4, pix6, cb, s_out);
         if (tap_off >= 0 && p.taps && v4) put_f32(acc, p.taps + (size_t)n * 6144 + tap_off + m4 * 64 + cb);
       }
     };
-    conv4(D3p, nullptr, w_b0, 4, 2, nullptr, E, -1, w_b3, 5 * wm_s);
+    float s_tmp, i_tmp, s_b3, i_b3;
+    conv4(D3p, nullptr, w_b0, 4, 2, nullptr, E, -1, w_b3, 5 * wm_s, i_d3, 1.f, s_tmp, i_tmp);
     LR_STAMP(5);
-    conv4(E, nullptr, w_b3, 5, -1, nullptr, Fb, 1024, w_u1c1, 0);
+    conv4(E, nullptr, w_b3, 5, -1, nullptr, Fb, 1024, w_u1c1, 0, 1.f, 1.f, s_b3, i_b3);
     LR_STAMP(6);
-    conv4(Fb, D3p, w_u1c1, 6, 3, sm + SM_TEMB + 1 * 64, E, -1, w_u1c2, 5 * wm_s);
+    conv4(Fb, D3p, w_u1c1, 6, 3, sm + SM_TEMB + 1 * 64, E, -1, w_u1c2, 5 * wm_s, i_b3, i_d3, s_tmp, i_tmp);
     LR_STAMP(7);
-    conv4(E, nullptr, w_u1c2, 7, 4, nullptr, Fb, -1, w_u1t, 2 * wm_s * 4);
+    conv4(E, nullptr, w_u1c2, 7, 4, nullptr, Fb, -1, w_u1t, 2 * wm_s * 4, 1.f, 1.f, s_tmp, i_tmp);
     LR_STAMP(8);
 
     // ================= I: up1.transform, ConvTranspose2d 4x4 s2 p1, 4x4 -> 8x8: output parities 2wm, 2wm+1 per wave pair =================
@@ -712,17 +826,19 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       krun<NA>(acc1, wf, au, PL4, w_u1t, lane16, 4, [&](int t, int& ao, int& wt) { ao = ((wm_s + (t >> 1)) * 6 + 1 + (t & 1)) * RSB; wt = (par0 + 1) * 4 + t; });
     }
     kload<NA, 2>(wf, w_u2c1a, 0, lane16);
-    add_bias(acc, bias_t + 8 * 64, cb);
-    add_bias(acc1, bias_t + 8 * 64, cb);
+    scale_bias(acc, wsc[8], bias_t + 8 * 64, cb);
+    scale_bias(acc1, wsc[8], bias_t + 8 * 64, cb);
     if (p.taps && v4) {
       put_f32(acc, p.taps + (size_t)n * 6144 + 2048 + ((2 * y4 + wm) * 8 + 2 * x4) * 64 + cb);
       put_f32(acc1, p.taps + (size_t)n * 6144 + 2048 + ((2 * y4 + wm) * 8 + 2 * x4 + 1) * 64 + cb);
     }
-    __syncthreads();  // every wave is done with F: P becomes the 10x10 layout again
+    float s_u1 = 1.f, i_u1 = 1.f;   // scale of up1's output as planes
+    if constexpr (NA == 2) s_u1 = wg_scale(v4 ? fmaxf(lane_amax(acc), lane_amax(acc1)) : 0.f, red4, wave, i_u1);
+    else __syncthreads();  // every wave is done with F: P becomes the 10x10 layout again (NA = 2: wg_scale's barrier)
     zero_ring<NA, 10>(P, PL);
     if (v4) {  // up1's output, raw: first input of up2.conv1 (parity py = wm, px = 0 / 1)
-      put_planes<NA>(acc, P, PL, (2 * y4 + wm + 1) * 10 + 2 * x4 + 1, cb);
-      put_planes<NA>(acc1, P, PL, (2 * y4 + wm + 1) * 10 + 2 * x4 + 2, cb);
+      put_planes<NA>(acc, P, PL, (2 * y4 + wm + 1) * 10 + 2 * x4 + 1, cb, s_u1);
+      put_planes<NA>(acc1, P, PL, (2 * y4 + wm + 1) * 10 + 2 * x4 + 2, cb, s_u1);
     }
 
     LR_STAMP(9);
@@ -740,17 +856,22 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     }
     krun2<NA, 2>(acc, acc1, wf, a8a, a8b, PL, w_u2c1a, lane16, 9, tap3_10);
     kload<NA, 2>(wf, w_u2c1b, 0, lane16);
+    if constexpr (NA == 2) {  // the sums over up1's channels move to the scale of down2's planes (powers of two: exact)
+      const float rs = i_u1 * s_d2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[r] *= rs; acc1[r] *= rs; }
+    }
     __syncthreads();  // the up1 planes are consumed
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int idx = tid + 256 * u, pix = idx >> 3, c8 = idx & 7;
-      put_planes8<NA>(d2v[u][0], d2v[u][1], P + (((pix >> 3) + 1) * 10 + (pix & 7) + 1) * RSB + c8 * 8, PL);
+      put_planes8<NA>(d2v[u][0], d2v[u][1], P + (((pix >> 3) + 1) * 10 + (pix & 7) + 1) * RSB + c8 * 8, PL, s_d2);
     }
     __syncthreads();
     krun2<NA, 2>(acc, acc1, wf, a8a, a8b, PL, w_u2c1b, lane16, 9, tap3_10);
     kload<NA, 2>(wf, w_u2c2, 0, lane16);
     kx_exchange(acc, acc1, wm, wave, lane, X8);
-    add_bias(acc, bias_t + 9 * 64, cb);
+    scale_bias(acc, wsc[9] * i_d2, bias_t + 9 * 64, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 5 * 64, sm + SM_BETA + 5 * 64, sm + SM_TEMB + 2 * 64, cb, red, wave, wn);
     put_planes<NA>(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
     LR_STAMP(10);
@@ -760,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     krun2<NA, 2>(acc, acc1, wf, a8a, a8b, PL, w_u2c2, lane16, 9, tap3_10);
     kload<NA>(wf, w_u2t, 2 * wm_s * 4, lane16);
     kx_exchange(acc, acc1, wm, wave, lane, X8);
-    add_bias(acc, bias_t + 10 * 64, cb);
+    scale_bias(acc, wsc[10], bias_t + 10 * 64, cb);
     gn_silu_regs<2>(acc, true, 1.0f / 512.0f, sm + SM_GAMMA + 6 * 64, sm + SM_BETA + 6 * 64, nullptr, cb, red, wave, wn);
     put_planes<NA>(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb);
 
@@ -779,8 +900,8 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
                  [&](int t, int& ao, int& wt) { ao = ((py + (t >> 1)) * 10 + px + (t & 1)) * RSB; wt = par * 4 + t; });
         if (pp == 0) kload<NA>(wf, w_u2t, (par + 1) * 4, lane16);
         else if (n + (int)gridDim.x < p.B) kload<NA, 2>(wf, w_d2t, wt_phase(0, 0, 0, 0), lane16);  // the next image's first fragments
-        add_bias(acc, bias_t + 11 * 64, cb);
-        add_bias(acc1, bias_t + 11 * 64, cb);
+        scale_bias(acc, wsc[11], bias_t + 11 * 64, cb);
+        scale_bias(acc1, wsc[11], bias_t + 11 * 64, cb);
         const size_t oa = (((size_t)n * 16 + 2 * y8a + py) * 16 + 2 * x8l + px) * 64 + cb;
         const size_t ob = (((size_t)n * 16 + 2 * y8b + py) * 16 + 2 * x8l + px) * 64 + cb;
         if constexpr (NA == 1) {

@@ -2,7 +2,7 @@
 MFMAs per product, fp32 accumulation) through the C ABI against stock torch-CPU fp32 ops — to the SAME bounds as the
 fp32-MFMA kernels (tests/test_gpu_kernels.py): the arithmetic is fp32-equivalent, not a reduced-precision mode.
 kinds 7 / 8 / 9 = Conv2d 3x3 (model.py:41,45), Conv2d 4x4 stride 2 (model.py:46), ConvTranspose2d 4x4 stride 2 (model.py:43).
-kinds 13 / 14 = kinds 8 / 9 with the operands as TWO fp16 terms (three MFMAs per product), for inputs behind a GroupNorm - the
+kinds 13 / 14 / 15 = kinds 8 / 9 / 7 with the operands as TWO fp16 terms (three MFMAs per product), for inputs behind a GroupNorm - the
 model's default for its stride-2 / transposed convolutions; same bounds."""
 import pytest
 import torch
@@ -20,7 +20,7 @@ def run_x6(kind, x1, x2, w, b, tf=None, want_stats=True):
     c2 = 0 if x2 is None else x2.shape[1]
     cin = c1 + c2
     cout = w.shape[1] if kind in (9, 14) else w.shape[0]
-    OH, OW = (H, W) if kind == 7 else (H // 2, W // 2) if kind in (8, 13) else (2 * H, 2 * W)
+    OH, OW = (H, W) if kind in (7, 15) else (H // 2, W // 2) if kind in (8, 13) else (2 * H, 2 * W)
     wp = torch.empty(L.dm_conv_packed_floats(kind, cin, cout), device=DEV)
     wd = w.to(DEV).contiguous()
     _lib.check(L.dm_pack_conv_weight(kind, _lib.ptr(wd), cin, cout, _lib.ptr(wp), stream()))
@@ -42,7 +42,7 @@ def run_x6(kind, x1, x2, w, b, tf=None, want_stats=True):
 
 
 def ref_conv(kind, x, w, b):
-    return (F.conv2d(x, w, b, padding=1) if kind == 7 else F.conv2d(x, w, b, stride=2, padding=1) if kind in (8, 13)
+    return (F.conv2d(x, w, b, padding=1) if kind in (7, 15) else F.conv2d(x, w, b, stride=2, padding=1) if kind in (8, 13)
             else F.conv_transpose2d(x, w, b, stride=2, padding=1))
 
 
@@ -93,7 +93,8 @@ def test_x6_conv_wide_and_concat(kind, B, H, cin, cout):
     check_stats(st, ref, B)
 
 
-@pytest.mark.parametrize("kind,H", [(7, 32), (8, 32), (9, 16), (8, 16), (9, 8), (7, 4), (13, 32), (14, 16), (13, 16), (14, 8), (13, 64), (14, 32)])
+@pytest.mark.parametrize("kind,H", [(7, 32), (8, 32), (9, 16), (8, 16), (9, 8), (7, 4), (13, 32), (14, 16), (13, 16), (14, 8), (13, 64), (14, 32),
+                                    (15, 32), (15, 16), (15, 8), (15, 64)])
 def test_x6_conv_fused_groupnorm_silu_temb(kind, H):
     """Input transform SiLU(GroupNorm8(x)) + temb applied while staging (model.py:54-62), from producer partials."""
     torch.manual_seed(kind + H)
@@ -105,7 +106,7 @@ def test_x6_conv_fused_groupnorm_silu_temb(kind, H):
     st0 = torch.stack([mean, ((hg - mean[:, :, None]) ** 2).sum(2)], dim=-1).reshape(B, 1, 8, 2)
     gamma, beta, temb = torch.rand(64) + 0.5, torch.randn(64) * 0.1, torch.randn(1, 64)
     tf = (st0.to(DEV), 1, float(H * H * 8), gamma.to(DEV), beta.to(DEV), temb.to(DEV), 0)
-    k = 3 if kind == 7 else 4
+    k = 3 if kind in (7, 15) else 4
     w, b = torch.randn(64, 64, k, k) * 0.05, torch.randn(64)
     y, st = run_x6(kind, h_raw, None, w, b, tf=tf)
     hin = F.silu(F.group_norm(h_raw, 8, gamma, beta, eps=1e-5)) + temb[:, :, None, None]
@@ -131,8 +132,8 @@ def test_x6_split_keeps_fp32_accuracy_on_badly_scaled_inputs():
 def test_x6_rows_of_a_large_batch_match_a_small_batch():
     """Persistent workgroups walk many tiles (XCD-aware order): rows of a B=600 launch == the same rows alone, bit for bit."""
     torch.manual_seed(9)
-    for kind, H in ((7, 16), (8, 32), (9, 16), (13, 32), (14, 16)):
-        k = 3 if kind == 7 else 4
+    for kind, H in ((7, 16), (8, 32), (9, 16), (13, 32), (14, 16), (15, 32)):
+        k = 3 if kind in (7, 15) else 4
         x = torch.randn(600, 64, H, H)
         w, b = torch.randn(64, 64, k, k) * 0.05, torch.randn(64)
         tf = tf2 = None
@@ -172,8 +173,9 @@ def test_fp16_form_weight_scaling(scale):
     gamma, beta, temb = torch.rand(64) + 0.5, torch.randn(64) * 0.1, torch.randn(1, 64)
     tf = (st0.to(DEV), 1, float(H * H * 8), gamma.to(DEV), beta.to(DEV), temb.to(DEV), 0)
     hin = F.silu(F.group_norm(h_raw, 8, gamma, beta, eps=1e-5)) + temb[:, :, None, None]
-    for kind in (13, 14):
-        w, b = torch.randn(64, 64, 4, 4) * 0.05 * scale, torch.randn(64) * scale
+    for kind in (13, 14, 15):
+        k = 3 if kind == 15 else 4
+        w, b = torch.randn(64, 64, k, k) * 0.05 * scale, torch.randn(64) * scale
         y, _ = run_x6(kind, h_raw, None, w, b, tf=tf, want_stats=False)
         ref = ref_conv(kind, hin.double(), w.double(), b.double())
         assert (y.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
@@ -181,7 +183,8 @@ def test_fp16_form_weight_scaling(scale):
 
 def test_x6_model_forward_matches_fp32_mfma_forward_and_oracle(monkeypatch):
     """UNetMini.forward (model.py:120-151) with the 4x4 convolutions on the bf16 pipe (three-way bf16 split, DM_X6=7; the
-    default DM_X6=39 takes two fp16 terms for the layers behind a GroupNorm) against the same weights on the fp32-MFMA
+    default DM_X6=231 takes two fp16 terms: stride-2 / transposed convs and every conv2 behind a GroupNorm, and all twelve
+    layers of the fused low-resolution kernel) against the same weights on the fp32-MFMA
     kernels only (DM_X6=0) and against the CPU oracle: the split forms move eps by less than the fp32 kernels' own distance
     from the oracle."""
     import diffusion_model_amd as d
@@ -194,7 +197,7 @@ def test_x6_model_forward_matches_fp32_mfma_forward_and_oracle(monkeypatch):
     m7 = d.UNetMini(image_size=32).eval()
     m7._native()
     m7.load_state_dict(m0.state_dict())
-    monkeypatch.setenv("DM_X6", "39")
+    monkeypatch.setenv("DM_X6", "231")
     m39 = d.UNetMini(image_size=32).eval()
     m39._native()
     m39.load_state_dict(m0.state_dict())

@@ -1,8 +1,8 @@
 # the fp16 two-term form of the stride-2 / transposed convolutions (default, DM_X6=39) against the three-way bf16 split (DM_X6=7)
 mkdir -p gpurun_out/r3f16
-timeout -k 10 300 python -u -m pytest tests/test_gpu_x6.py -x -q -s --timeout 120 --timeout-method thread > gpurun_out/r3f16/test.log 2>&1 || { tail -40 gpurun_out/r3f16/test.log; exit 1; }
+timeout -k 10 300 python -u -m pytest tests/test_gpu_x6.py tests/test_gpu_lowres.py -x -q -s --timeout 120 --timeout-method thread > gpurun_out/r3f16/test.log 2>&1 || { tail -40 gpurun_out/r3f16/test.log; exit 1; }
 grep -E "eps error|passed|failed" gpurun_out/r3f16/test.log
-for x in 39 7; do
+for x in 231 103; do
   for B in 1024 64; do
     DM_X6=$x timeout -k 10 100 python - <<PY || exit 1
 import torch, sys
