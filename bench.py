@@ -45,13 +45,20 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 K_NAMES = ["init_conv", "conv3x3_mfma_t128", "conv3x3_mfma_t64", "conv4x4s2_mfma", "convT4x4s2_mfma_t128",
            "convT4x4s2_mfma_t64", "final_conv", "time_embed", "sampler_step", "attention", "conv3x3_winograd_mfma",
-           "conv3x3_bf16x6_mfma", "conv4x4s2_bf16x6_mfma", "convT4x4s2_bf16x6_mfma", "conv_any_geometry_mfma", "groupnorm_silu_any_geometry",
-           "lowres_fused_bf16x6_mfma"]
+           "conv3x3_split16_mfma", "conv4x4s2_split16_mfma", "convT4x4s2_split16_mfma", "conv_any_geometry_mfma", "groupnorm_silu_any_geometry",
+           "lowres_fused_split16_mfma"]
 NK = len(K_NAMES)  # DM_K_COUNT
 K_WINO = 10
 MFMA_CLASSES = (1, 2, 3, 4, 5, 9, 10, 11, 12, 13)
 MFMA_CLASSES = MFMA_CLASSES + (14,)
-X6_CLASSES = (11, 12, 13, 16)  # fp32 convolutions on the bf16 pipe: six bf16 MFMAs per fp32 product (three-way split operands)
+# fp32 convolutions on the 16-bit matrix pipe, operands split into 16-bit terms: class -> the DM_X6 bit that selects the two-fp16-term
+# form (THREE v_mfma_f32_32x32x16_f16 per fp32 product; default) in place of the three-bf16-term form (SIX bf16 MFMAs)
+X6_CLASSES = {11: 64, 12: 32, 13: 32, 16: 128}
+DM_X6 = int(os.environ.get("DM_X6", "487"))
+
+
+def split16_mfmas_per_product(k):
+    return 3 if (DM_X6 & 16) or (DM_X6 & X6_CLASSES[k]) else 6
 # PMC / rocprofv3 summaries of THIS build (profiles/README.md): each file carries the key of the library it was measured on
 # (`build_key`, __graft_entry__.build_key()); a figure whose key differs from the loaded library's is reported as null
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r3_traffic.json")
@@ -99,9 +106,11 @@ def profile_model(model, sched, B, H, W, reps=3):
             tf = fl[k] / (ms[k] * 1e-3) / 1e12
             e = {"launches": counts[k] // reps, "avg_us": 1e3 * ms[k] / counts[k], "share": ms[k] / tot_ms, "tflops": tf,
                  "alg_gbps": by[k] / (ms[k] * 1e-3) / 1e9}
-            if k in X6_CLASSES and not bf16:  # executed bf16 MFMA FLOPs = 6 x the algorithmic fp32 FLOPs, priced on the bf16 peak
-                e["executed_mfma_frac"] = tf * 6.0 / PEAK_BF16_MFMA_TFLOPS
-                e["pipe"] = "bf16 MFMA, three-way split operands (fp32-equivalent accuracy)"
+            if k in X6_CLASSES and not bf16:  # executed 16-bit MFMA FLOPs = 3 (6) x the algorithmic fp32 FLOPs, priced on the dense bf16 / fp16 peak
+                nm = split16_mfmas_per_product(k)
+                e["executed_mfma_frac"] = tf * nm / PEAK_BF16_MFMA_TFLOPS
+                e["pipe"] = ("fp16 MFMA, operands as two fp16 terms, three MFMAs per fp32 product" if nm == 3 else
+                             "bf16 MFMA, operands as three bf16 terms, six MFMAs per fp32 product") + " (fp32-equivalent accuracy)"
             elif k in MFMA_CLASSES:  # executed MFMA fraction (the Winograd class executes 4/9 of its algorithmic FLOPs)
                 e["executed_mfma_frac"] = tf * (4.0 / 9.0 if k == K_WINO else 1.0) / peak
             per[K_NAMES[k]] = e
@@ -472,14 +481,15 @@ def main():
     if rank == 0 and not args.no_roofline:  # (any N: rank 0's own kernels; the other ranks wait at the final barrier)
         per, raw = profile_model(model, sched, B, IMG, IMG, reps=10 if args.model == "mnist" else 3)
         counts, ms, fl, by, tot_ms = raw["counts"], raw["ms"], raw["fl"], raw["by"], raw["tot_ms"]
-        k = 1 if args.precision == "bf16" else K_WINO  # dominant: conv_bf16_kernel<2,0> / conv_mfma_kernel<2,5,64> (DM_K_WINO)
+        # dominant kernel class of the step (largest share of the denoiser's device time)
+        k = 1 if args.precision == "bf16" else max((q for q in range(NK) if counts[q] and q in MFMA_CLASSES), key=lambda q: ms[q])
         ach = fl[k] / (ms[k] * 1e-3) / 1e12
         # HBM bytes per launch from the committed PMC passes and the rocprofv3 class average, both only if measured on THIS build
         traffic = rocprof_avg = None
         if B == 1024 and args.precision == "fp32" and args.model == "mnist":
             tj, rj = keyed_profile(TRAFFIC_FILE), keyed_profile(ROCPROF_FILE)
-            traffic = tj.get("hbm_bytes_per_launch") if tj else None
-            rocprof_avg = rj.get("winograd_class_avg_us") if rj else None
+            traffic = tj.get("classes", {}).get(K_NAMES[k], {}).get("hbm_bytes_per_launch") if tj else None
+            rocprof_avg = rj.get("classes", {}).get(K_NAMES[k], {}).get("avg_us") if rj else None
         if args.precision == "bf16":
             # at 16x the MFMA rate the bf16 conv kernel is bound by its activation traffic
             gbps = by[k] / (ms[k] * 1e-3) / 1e9
@@ -488,12 +498,23 @@ def main():
                                "traffic": None, "avg_launch_us": 1e3 * ms[k] / counts[k],
                                "algorithmic_bytes_per_launch": by[k] / counts[k], "share_of_denoiser_time": ms[k] / tot_ms}
         else:
-            exe = ach * (4.0 / 9.0)
-            res["roofline"] = {"kernel": "conv_mfma_kernel<2,5,64> (3x3 conv as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)",
-                               "bound": "mfma", "achieved": exe, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": exe / PEAK_FP32_MFMA_TFLOPS,
-                               "note": "achieved/frac = EXECUTED MFMA FLOPs (the Winograd form executes 4/9 of the direct-conv FLOPs); "
-                                       "algorithmic_* price the direct-conv FLOPs of SURVEY 8(d) and may exceed the peak",
+            if k in X6_CLASSES:
+                nm = split16_mfmas_per_product(k)
+                exe, peak = ach * nm, PEAK_BF16_MFMA_TFLOPS
+                kname = {11: "conv_x6_kernel<2,0,true,2,true> / conv_x6_c3_kernel (3x3 conv, direct form", 12: "conv_x6_down_kernel (4x4 stride-2 conv",
+                         13: "conv_x6_kernel<2,4> (transposed 4x4 conv", 16: "lowres_fused_kernel (twelve layers at <= 8x8"}[k] + \
+                    (", fp32 operands as two fp16 terms on v_mfma_f32_32x32x16_f16)" if nm == 3 else ", fp32 operands as three bf16 terms on v_mfma_f32_32x32x16_bf16)")
+                note = (f"achieved/frac = EXECUTED 16-bit MFMA FLOPs ({nm} MFMAs per fp32 product) against the dense bf16/fp16 MFMA peak; "
+                        "algorithmic_* price the direct-conv fp32 FLOPs of SURVEY 8(d) against the fp32-MFMA peak and may exceed it")
+            else:
+                wino = k == K_WINO
+                exe, peak = ach * (4.0 / 9.0 if wino else 1.0), PEAK_FP32_MFMA_TFLOPS
+                kname = ("conv_mfma_kernel<2,5,64> (3x3 conv as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)" if wino else K_NAMES[k] + " (v_mfma_f32_32x32x2_f32)")
+                note = ("achieved/frac = EXECUTED MFMA FLOPs (the Winograd form executes 4/9 of the direct-conv FLOPs); "
+                        "algorithmic_* price the direct-conv FLOPs of SURVEY 8(d) and may exceed the peak")
+            res["roofline"] = {"kernel": kname, "class": K_NAMES[k],
+                               "bound": "mfma", "achieved": exe, "peak": peak, "unit": "TFLOP/s",
+                               "frac": exe / peak, "note": note,
                                "algorithmic_achieved": ach, "algorithmic_frac": ach / PEAK_FP32_MFMA_TFLOPS,
                                "traffic": traffic,
                                "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, B=1024)",
@@ -501,7 +522,7 @@ def main():
                                "avg_launch_us": 1e3 * ms[k] / counts[k], "flop_per_launch": fl[k] / counts[k],
                                "rocprof_avg_launch_us": rocprof_avg,
                                "rocprof_note": "rocprofv3 --kernel-trace --stats class average of the same command on this build "
-                                               "(profiles/r3_cfg2_kernel_stats.csv); null when the committed profile is of another build",
+                                               "(profiles/r3_rocprof_summary.json); null when the committed profile is of another build",
                                "launches_per_evaluation": counts[k] // (10 if args.model == "mnist" else 3),
                                "share_of_denoiser_time": ms[k] / tot_ms}
         res["kernels"] = per

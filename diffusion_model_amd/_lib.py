@@ -47,6 +47,7 @@ _SIGS = {
     "dm_pack_conv_weight": (_i, [_i, _vp, _i, _i, _vp, _vp]),
     "dm_conv_stats_partials": (_i, [_i, _i, _i]),
     "dm_debug_lowres_taps": (None, [_vp]),
+    "dm_debug_conv_amax": (None, [_vp, _i, _vp, _i, _vp]),
     "dm_groupnorm_silu": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "dm_conv2d": (_i, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _i, _vp, _vp,
                        _i, _i, _i, _vp]),

@@ -129,7 +129,7 @@ unsigned long long* g_stamps = nullptr;  // diagnostic build: set through dm_deb
 #endif
 
 #ifndef DM_X6_DEFAULT
-#define DM_X6_DEFAULT 231
+#define DM_X6_DEFAULT 487
 #endif
 struct ConvCall {
   int kind;
@@ -146,6 +146,8 @@ struct ConvCall {
   const float* res; int no_silu;
   int bf16;  // activations and packed weights are bf16 (conv_bf16_kernel)
   int in_wrap;  // input images n >= in_wrap read image n - in_wrap (3x3 Winograd / bf16 3x3 kernel, one image per tile)
+  const float* amax1; const float* amax2; int namax1, namax2;  // x6 == 3 on raw inputs: the producers' maxima (ConvArgs.amax1)
+  float* amax_out;                                            // x6 kernels, tiles of one image: maxima of this launch's output
   int x6;    // fp32 activations, weights packed as three bf16 split terms (conv_x6_kernel); kinds 0, 1/6, 2; 2: two-term form (opt-in);
              // 3: two fp16 terms (kinds 1/6, 2 behind a GroupNorm, one image per tile; the pack is pack_conv's kind 13 / 14)
   const float* init_x; const float* init_w; const float* init_b; int init_cin;  // folded init_conv
@@ -259,6 +261,7 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   a.stats_in = c.stats_in; a.gamma = c.gamma; a.beta = c.beta; a.temb = c.temb;
   a.step_ptr = c.step_ptr; a.stats_out = c.stats_out; a.cnt_in = c.cnt_in; a.pin = c.pin;
   a.temb_stride = c.temb_stride; a.temb_step_stride = c.temb_step_stride; a.step_off = c.step_off;
+  a.amax1 = c.amax1; a.amax2 = c.amax2; a.namax1 = c.namax1; a.namax2 = c.namax2; a.amax_out = c.amax_out;
   a.B = c.B; a.H = c.H; a.W = c.W; a.C1 = c.c1; a.C2 = c.c2; a.Cout = c.cout;
   a.Hb = g.Hb; a.Wb = g.Wb; a.th_log = g.th_log; a.tw_log = g.tw_log; a.ni = g.ni;
   a.tiles_x = g.tiles_x; a.tiles_per_img = g.tiles_per_img; a.hth = g.hth; a.htw = g.htw;
@@ -277,8 +280,9 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
   const int ns = c.x6 >= 2 ? 2 : 3;  // split terms per operand
   const bool f16 = c.x6 == 3;        // two fp16 terms (inputs behind a GroupNorm)
-  if (f16 && (!c.stats_in || g.ni != 1 || getenv("DM_DEBUG_NOSWAP")))
-    return fail("conv (fp16 split): convolutions behind a GroupNorm, tiles of one image");
+  if (f16 && ((!c.stats_in && !(kind == 0 && c.amax1 && (!c.c2 || c.amax2))) || g.ni != 1 || getenv("DM_DEBUG_NOSWAP")))
+    return fail("conv (fp16 split): inputs behind a GroupNorm (or, 3x3: raw inputs with their producers' maxima), tiles of one image");
+  if (c.amax_out && g.ni != 1) return fail("conv: output maxima need tiles of one image");
   size_t lds_f = (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (ns * np * 72 + 1) / 2 + 128;  // + reduction words behind the planes
   if (lds_f < epi_f) lds_f = epi_f;
   const size_t lds = lds_f * sizeof(float);
@@ -556,6 +560,8 @@ namespace {
 struct Workspace {
   float *A0, *T1, *T2, *D1, *D2, *D3, *BT0, *BT, *U1, *U2, *SA, *SB, *heads, *temb, *eps, *xx;
   float *xcur, *coefs, *cond, *noise;  // dm_sample's staged operands (graph nodes only see workspace addresses)
+  float* AM[4];         // per-wave maxima of |.| of D1, D2, U1, U2, [B][amax_cap] (ConvArgs.amax1): scales of the two-fp16-term conv1
+  size_t amax_cap;
   int64_t* ts;
   int* step;
   size_t stats_floats;  // capacity of SA and of SB
@@ -590,6 +596,12 @@ bool tuned_geometry(const dm_unet* m, int H, int W) { return m->fast && is_pow2(
 // terms (conv_x6_kernel<.., 0, true, 2, true>)?  Where DM_X6 bit 6 asks for it and a tile holds one image; by geometry only.
 bool conv2_f16(const dm_unet* m, int h, int ww, bool shared_input) {
   return !m->bf16 && (m->x6 & 64) && !(m->x6 & 16) && m->fast && !shared_input && h * ww >= 64 && is_pow2(h) && is_pow2(ww);
+}
+
+// ... and a block's conv1 (raw inputs: its producers' maxima give the power-of-two scale), DM_X6 bit 8?  (Not down1.conv1: that
+// one is part of init5_kernel.)
+bool conv1_f16(const dm_unet* m, int h, int ww) {
+  return !m->bf16 && (m->x6 & 256) && !(m->x6 & 16) && m->fast && h * ww >= 64 && is_pow2(h) && is_pow2(ww);
 }
 
 // Is the sampler update folded into final_conv's store (FinalStep)?  fp32, C = 64, tuned geometry, no guidance (the caller's part).
@@ -629,6 +641,8 @@ Workspace carve(const dm_unet* m, void* base, int B, int H, int W, int nsteps, s
   w.stats_floats = (size_t)B * (tuned_geometry(m, H, W) ? max_stats_partials(H, W, m->C) : 1) * DM_GROUPS * 2;
   w.SA = take(w.stats_floats);
   w.SB = take(w.stats_floats);
+  w.amax_cap = (tuned_geometry(m, H, W) && !m->bf16) ? (size_t)4 * ((m->C + 63) / 64) * max_stats_partials(H, W, m->C) : 0;
+  for (int i = 0; i < 4; ++i) w.AM[i] = w.amax_cap ? take((size_t)B * w.amax_cap) : nullptr;
   const size_t nt = (size_t)(nsteps > B ? nsteps : B);
   w.heads = take(nt * 6 * m->C);
   w.temb = take(nt * m->E);
@@ -948,8 +962,8 @@ bool uses_lowres(const dm_unet* m, int H, int W) {
 }
 
 int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float* st2, int pin2, float cnt2, const float* heads,
-                  int heads_img_stride, int heads_step_stride, const int* step_ptr, int step_off, float* d2, float* u2, int B,
-                  hipStream_t s) {
+                  int heads_img_stride, int heads_step_stride, const int* step_ptr, int step_off, float* d2, float* u2, float* amax_u2,
+                  int B, hipStream_t s) {
   LowresArgs a;
   memset(&a, 0, sizeof a);
   // wtot > 0: the pack is two fp16 planes of wtot elements with the float that undoes its power-of-two scale behind them
@@ -982,6 +996,7 @@ int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float
   a.heads = heads; a.heads_img_stride = heads_img_stride; a.heads_step_stride = heads_step_stride;
   a.step_ptr = step_ptr; a.step_off = step_off; a.d2 = d2; a.u2 = u2; a.B = B;
   a.taps = g_lowres_taps;
+  a.amax_u2 = amax_u2;
 #ifdef DM_STAMPS
   a.stamps = g_stamps;
 #endif
@@ -1051,13 +1066,19 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   const int xmode = (x6 & 16) ? 2 : 1;  // bit 4: two-term splits (three MFMAs per product; about 7x the fp32 rounding error) - opt-in
   auto x3 = [&](int h, int ww) { return h * ww >= 16 && ((x6 & 8) || ((x6 & 4) && (h < 8 || ww < 8))); };
   auto k3 = [&](int h, int ww) { return (!m->bf16 && !x3(h, ww) && h >= 8 && ww >= 8) ? 5 : 0; };
+  struct AmaxRef { const float* p; int n; };   // a tensor's maxima as its producer wrote them (null: none)
+  const AmaxRef no_amax = {nullptr, 0};
   auto block = [&](int k, const float* in1, const float* in2, int h, int ww, bool up, float* out, float* out_stats,
-                   bool convs_only = false) -> int {
+                   bool convs_only, AmaxRef a1, AmaxRef a2, float* am_buf, AmaxRef* am_out) -> int {
     const BlockOff& o = m->blk[k];
     const int kd = k3(h, ww);
     const bool xs = x3(h, ww);
-    base(kd, in1, C, in2, in2 ? C : 0, xs ? o.c1x : kd == 5 ? o.c1w : o.c1, o.c1b, w.T1, w.SA, h, ww);
-    c.x6 = xs ? xmode : 0;
+    // conv1 reads its inputs raw: two fp16 terms where the producers left their maxima (conv1_f16), else Winograd / direct
+    const bool c1h = k != 0 && !xs && conv1_f16(m, h, ww) && a1.p && (!in2 || a2.p);
+    const int k1 = c1h ? 0 : kd;
+    base(k1, in1, C, in2, in2 ? C : 0, c1h ? o.c1h : xs ? o.c1x : kd == 5 ? o.c1w : o.c1, o.c1b, w.T1, w.SA, h, ww);
+    c.x6 = c1h ? 3 : xs ? xmode : 0;
+    if (c1h) { c.amax1 = a1.p; c.namax1 = a1.n; c.amax2 = in2 ? a2.p : nullptr; c.namax2 = in2 ? a2.n : 0; }
     if (k == 0 && fold_init) {
       c.init_x = x; c.init_w = P + m->o_initw; c.init_b = P + m->o_initb; c.init_cin = m->Cin;
     }
@@ -1075,7 +1096,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     base(k2, w.T1, C, nullptr, 0, c2h ? o.c2h : xs ? o.c2x : k2 == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
     c.x6 = c2h ? 3 : xs ? xmode : 0;  // (c2h implies h * w >= 64, where xs is off unless DM_X6 bit 3 is set)
     c.in_wrap = shared1 ? dup_half : 0;
-    with_tf(w.SA, kd, h, ww, o.g1, o.b1);
+    with_tf(w.SA, k1, h, ww, o.g1, o.b1);
     c.temb = heads + (size_t)k * C; c.temb_stride = heads_img_stride; c.temb_step_stride = heads_step_stride;
     c.step_ptr = step_ptr; c.step_off = step_off;
     if (launch_conv(c, s)) return 1;
@@ -1094,27 +1115,35 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     base(up ? 2 : kdn, w.T2, C, nullptr, 0, xh ? o.trh : xt ? o.trx : o.tr, o.trb, out, out_stats, h, ww);
     c.x6 = xh ? 3 : xt ? xmode : 0;
     with_tf(w.SB, k2, h, ww, o.g2, o.b2);
+    if (am_out) *am_out = no_amax;
+    if (am_buf && am_out && xt && gt.ni == 1 && !getenv("DM_DEBUG_NOSWAP")) {  // (the swapped epilogue writes them)
+      c.amax_out = am_buf;
+      *am_out = AmaxRef{am_buf, gt.pout * (C / 64) * 4};
+    }
     return launch_conv(c, s);
   };
-  if (block(0, w.A0, nullptr, H, W, false, w.D1, nullptr)) return 1;
+  AmaxRef aD1 = no_amax, aD2 = no_amax, aU1 = no_amax, aU2 = no_amax;
+  if (block(0, w.A0, nullptr, H, W, false, w.D1, nullptr, false, no_amax, no_amax, w.AM[0], &aD1)) return 1;
   if (uses_lowres(m, H, W)) {
     // everything at and below 8x8 pixels - down2.transform ... up2.transform, twelve layers - in ONE launch with the
     // activations in LDS (dm_kernels_lowres.hip); chosen by geometry only, so results do not depend on the batch
-    if (block(1, w.D1, nullptr, H / 2, W / 2, false, nullptr, nullptr, true)) return 1;
+    if (block(1, w.D1, nullptr, H / 2, W / 2, false, nullptr, nullptr, true, aD1, no_amax, nullptr, nullptr)) return 1;
     const ConvGeo pg = conv_geo(conv2_f16(m, H / 2, W / 2, false) ? 0 : k3(H / 2, W / 2), H / 2, W / 2, C);
-    if (launch_lowres(m, P, w.T2, w.SB, pg.pout, pg.cnt_out, heads, heads_img_stride, heads_step_stride, step_ptr, step_off, w.D2, w.U2, B, s))
+    if (launch_lowres(m, P, w.T2, w.SB, pg.pout, pg.cnt_out, heads, heads_img_stride, heads_step_stride, step_ptr, step_off, w.D2, w.U2, w.AM[3], B, s))
       return 1;
-    if (block(5, w.U2, w.D1, H / 2, W / 2, true, w.A0, w.SA)) return 1;
+    if (w.AM[3]) aU2 = AmaxRef{w.AM[3], 4};
+    if (block(5, w.U2, w.D1, H / 2, W / 2, true, w.A0, w.SA, false, aU2, aD1, nullptr, nullptr)) return 1;
     const ConvGeo pf = conv_geo(2, H / 2, W / 2, C);
     return launch_final(w.A0, m->bf16, w.SA, pf.pout, pf.cnt_out, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H, W, C,
                         m->Cout, s, fstep);
   }
-  if (block(1, w.D1, nullptr, H / 2, W / 2, false, w.D2, m->attn ? w.SA : nullptr)) return 1;
+  if (block(1, w.D1, nullptr, H / 2, W / 2, false, w.D2, m->attn ? w.SA : nullptr, false, aD1, no_amax, w.AM[1], &aD2)) return 1;
+  if (m->attn) aD2 = no_amax;  // (the attention block rewrites D2)
   if (m->attn) {
     const ConvGeo pg = conv_geo((!m->bf16 && (H / 4) * (W / 4) >= 256) ? 6 : 1, H / 2, W / 2, C);  // down2.transform
     if (attention_block(m, P, 0, w.D2, w.SA, pg.pout, pg.cnt_out, w, B, H / 4, W / 4, H, W, s)) return 1;
   }
-  if (block(2, w.D2, nullptr, H / 4, W / 4, false, w.D3, nullptr)) return 1;
+  if (block(2, w.D2, nullptr, H / 4, W / 4, false, w.D3, nullptr, false, aD2, no_amax, nullptr, nullptr)) return 1;
   // bottleneck (model.py:98-103,143)
   const int kb = k3(H / 8, W / 8);
   const bool xb = x3(H / 8, W / 8);
@@ -1126,13 +1155,14 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
   with_tf(w.SA, kb, H / 8, W / 8, m->o_bg, m->o_bb);
   if (launch_conv(c, s)) return 1;
   // up path: channel concat [upstream, skip] (model.py:146-148) handled by two input pointers
-  if (block(3, w.BT, w.D3, H / 8, W / 8, true, w.U1, m->attn ? w.SA : nullptr)) return 1;
+  if (block(3, w.BT, w.D3, H / 8, W / 8, true, w.U1, m->attn ? w.SA : nullptr, false, no_amax, no_amax, w.AM[2], &aU1)) return 1;
+  if (m->attn) aU1 = no_amax;
   if (m->attn) {
     const ConvGeo pg = conv_geo(2, H / 8, W / 8, C);
     if (attention_block(m, P, 1, w.U1, w.SA, pg.pout, pg.cnt_out, w, B, H / 4, W / 4, H, W, s)) return 1;
   }
-  if (block(4, w.U1, w.D2, H / 4, W / 4, true, w.U2, nullptr)) return 1;
-  if (block(5, w.U2, w.D1, H / 2, W / 2, true, w.A0, w.SA)) return 1;
+  if (block(4, w.U1, w.D2, H / 4, W / 4, true, w.U2, nullptr, false, aU1, aD2, w.AM[3], &aU2)) return 1;
+  if (block(5, w.U2, w.D1, H / 2, W / 2, true, w.A0, w.SA, false, aU2, aD1, nullptr, nullptr)) return 1;
   {  // final_conv (model.py:111-115,151)
     const ConvGeo pg = conv_geo(2, H / 2, W / 2, C);
     if (launch_final(w.A0, m->bf16, w.SA, pg.pout, pg.cnt_out, P + m->o_fg, P + m->o_fb, P + m->o_fw, P + m->o_fwb, eps, B, H, W,
@@ -1282,7 +1312,7 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
   m->attn = attention ? 1 : 0;
   m->bf16 = 0;
   m->fast = fast ? 1 : 0;
-  m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 255 : DM_X6_DEFAULT;
+  m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 511 : DM_X6_DEFAULT;
   m->init5 = getenv("DM_INIT5") ? (atoi(getenv("DM_INIT5")) != 0) : 1;
   m->lowres = getenv("DM_LOWRES") ? (atoi(getenv("DM_LOWRES")) != 0) : 1;
   const int C = m->C, E = m->E;
@@ -1706,6 +1736,12 @@ void dm_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
 
 void dm_debug_lowres_taps(float* taps_dev) { g_lowres_taps = taps_dev; }
 
+// tests: the maxima buffers of the NEXT dm_conv2d call (kinds 13-15; see ConvArgs.amax1 / amax_out), cleared by that call
+static const float* g_dbg_amax1 = nullptr; static const float* g_dbg_amax2 = nullptr; static int g_dbg_n1 = 0, g_dbg_n2 = 0; static float* g_dbg_amax_out = nullptr;
+void dm_debug_conv_amax(const float* amax1, int namax1, const float* amax2, int namax2, float* amax_out) {
+  g_dbg_amax1 = amax1; g_dbg_n1 = namax1; g_dbg_amax2 = amax2; g_dbg_n2 = namax2; g_dbg_amax_out = amax_out;
+}
+
 size_t dm_conv_packed_floats(int kind, int cin, int cout) { return conv_packed_floats(kind, cin, cout); }
 
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev, void* stream) {
@@ -1748,6 +1784,10 @@ int dm_conv2d(int kind, const float* x1, int c1, const float* x2, int c2, const 
   }
   if (kind >= 7 && kind <= 9) { c.x6 = 1; c.kind = x6_base_kind(kind, H, W); }
   if (kind >= 13 && kind <= 15) { c.x6 = 3; c.kind = x6_base_kind(kind, H, W); }
+  if (kind >= 7 && kind != 10 && kind != 11 && kind != 12) {
+    c.amax1 = g_dbg_amax1; c.namax1 = g_dbg_n1; c.amax2 = g_dbg_amax2; c.namax2 = g_dbg_n2; c.amax_out = g_dbg_amax_out;
+  }
+  g_dbg_amax1 = g_dbg_amax2 = nullptr; g_dbg_n1 = g_dbg_n2 = 0; g_dbg_amax_out = nullptr;
   return launch_conv(c, (hipStream_t)stream);
 }
 

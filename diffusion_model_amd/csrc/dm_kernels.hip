@@ -116,6 +116,12 @@ struct ConvArgs {
                           // both halves of the doubled batch share down1.conv1's output; one image per tile only)
   // init_conv folded into this conv's staging (KIND 0, down1.conv1): when init_x != null the input
   // tile is COMPUTED from the NCHW image (3x3 conv, init_cin -> C1 channels) instead of loaded
+  // two-fp16-term form on RAW inputs (conv_x6_kernel<.., F16>, stats_in == null): the producers' per-wave maxima of |x| per image,
+  // [B][namax]; the tile's image is scaled by a power of two taken from them.  amax_out: this launch writes such maxima of ITS
+  // output, [B][pout * (Cout / 64) * 4] (x6_epilogue_sw)
+  const float* amax1; const float* amax2;
+  int namax1, namax2;
+  float* amax_out;
   const float* init_x;    // [B, init_cin, H, W]
   const float* init_w;    // [C1, init_cin, 3, 3]
   const float* init_b;    // [C1]

@@ -54,6 +54,7 @@ struct LowresArgs {
 #ifdef DM_STAMPS
   unsigned long long* stamps;  // diagnostic build only: s_memtime stamps [grid][32] at entry 2^20 (the conv kernels stamp the front of the buffer) of the phases of the workgroup's LAST image
 #endif
+  float* amax_u2;        // null, or [B][4]: per-wave maxima of |u2| (the consumer's power-of-two scale, see ConvArgs.amax1)
   float* taps;           // null, or (tests) [B][2048 + 4096] raw fp32 NHWC: down3's output (4x4x64), the bottleneck's (4x4x64), up1's (8x8x64)
   int B;
 };
@@ -892,6 +893,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     {
       const bf16_t* u8a = P + (y8a * 10 + x8l) * RSB + 8 * h;
       const bf16_t* u8b = P + (y8b * 10 + x8l) * RSB + 8 * h;
+      float amx = 0.f;
       for (int pp = 0; pp < 2; ++pp) {
         const int par = 2 * wm_s + pp, py = wm_s, px = pp;
         zero_acc(acc);
@@ -902,6 +904,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
         else if (n + (int)gridDim.x < p.B) kload<NA, 2>(wf, w_d2t, wt_phase(0, 0, 0, 0), lane16);  // the next image's first fragments
         scale_bias(acc, wsc[11], bias_t + 11 * 64, cb);
         scale_bias(acc1, wsc[11], bias_t + 11 * 64, cb);
+        if (p.amax_u2) amx = fmaxf(amx, fmaxf(lane_amax(acc), lane_amax(acc1)));
         const size_t oa = (((size_t)n * 16 + 2 * y8a + py) * 16 + 2 * x8l + px) * 64 + cb;
         const size_t ob = (((size_t)n * 16 + 2 * y8b + py) * 16 + 2 * x8l + px) * 64 + cb;
         if constexpr (NA == 1) {
@@ -911,6 +914,15 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
           put_f32(acc, p.u2 + oa);
           put_f32(acc1, p.u2 + ob);
         }
+      }
+      if (p.amax_u2) {
+        amx = fmaxf(amx, __shfl_xor(amx, 32, 64));
+        amx = fmaxf(amx, __shfl_xor(amx, 16, 64));
+        amx = fmaxf(amx, __shfl_xor(amx, 8, 64));
+        amx = fmaxf(amx, __shfl_xor(amx, 4, 64));
+        amx = fmaxf(amx, __shfl_xor(amx, 2, 64));
+        amx = fmaxf(amx, __shfl_xor(amx, 1, 64));
+        if (lane == 0) p.amax_u2[(size_t)n * 4 + wave] = amx;
       }
     }
     LR_STAMP(12);

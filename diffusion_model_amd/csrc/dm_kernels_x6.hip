@@ -52,6 +52,24 @@ __device__ __forceinline__ void dm_split_h2(float a, float b, unsigned& s1, unsi
   v -= __builtin_convertvector(h, dm_f2);
   s2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, dm_h2v));
 }
+// Power-of-two scale of an image from its producers' maxima (every lane of the wave gets the same value): s = 2^k with
+// max|x| s in [2^10, 2^11), exponent clamped (an all-zero image keeps a finite scale); inv = 1 / s.
+__device__ __forceinline__ float dm_amax_scale(const float* a1, int n1, const float* a2, int n2, int lane, float& inv) {
+  float mx = 0.f;
+  for (int i = lane; i < n1; i += 64) mx = fmaxf(mx, a1[i]);
+  for (int i = lane; i < n2; i += 64) mx = fmaxf(mx, a2[i]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+  int eb = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+  eb = min(max(eb, 20), 240);
+  inv = __uint_as_float((unsigned)(eb - 10) << 23);
+  return __uint_as_float((unsigned)(264 - eb) << 23);
+}
+
 // one 32x32x16 MFMA on eight 16-bit elements per lane: bf16 or fp16 operands
 template <bool F16>
 __device__ __forceinline__ f32x16 dm_mfma16(const uint4& a, const uint4& b, const f32x16& c) {
@@ -80,6 +98,21 @@ __device__ __forceinline__ void x6_epilogue_sw(const ConvArgs& p, f32x16 (&acc)[
       acc[mb][4 * k] = fmaf(acc[mb][4 * k], oscale, bv.x); acc[mb][4 * k + 1] = fmaf(acc[mb][4 * k + 1], oscale, bv.y);
       acc[mb][4 * k + 2] = fmaf(acc[mb][4 * k + 2], oscale, bv.z); acc[mb][4 * k + 3] = fmaf(acc[mb][4 * k + 3], oscale, bv.w);  // (oscale = 1: the plain sum)
     }
+  }
+  if (p.amax_out) {  // largest |y| of this wave's part of the tile: the consumer's power-of-two scale (two-fp16-term form on raw inputs)
+    float mx = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[mb][r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    const int pidx = (UP ? par * p.tiles_per_img : 0) + tin;
+    if (lane == 0) p.amax_out[(((size_t)img0 * p.pout + pidx) * gridDim.y + blockIdx.y) * 4 + wave] = mx;
   }
   if (p.stats_out) {
     // channels per group G = 8 .. 64; this wave's 32 channels hold 32/G groups (G = 64: half a group)
@@ -237,6 +270,8 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
     const int y0 = (tin >> p.tx_log) << p.th_log;
     const int x0 = (tin & (p.tiles_x - 1)) << p.tw_log;
     DM_TL(1);
+    float ascale = 1.f, ainv = 1.f;  // F16 on raw inputs: the image's power-of-two scale
+    if constexpr (F16) if (!tf) ascale = dm_amax_scale(p.amax1 + (size_t)img0 * p.namax1, p.namax1, p.amax2 ? p.amax2 + (size_t)img0 * p.namax2 : nullptr, p.namax2, lane, ainv);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
       const int cch = (KIND == 1) ? chunk % cchunks : chunk;   // channel chunk
       const int ph = (KIND == 1) ? chunk / cchunks : 0;        // KIND 1: input phase (row parity a, column parity b)
@@ -325,6 +360,10 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
               }
               uint4 s1, s2, s3;
               if constexpr (F16) {
+                if (!tf) {
+#pragma unroll
+                  for (int k = 0; k < 8; ++k) e[k] *= ascale;
+                }
                 dm_split_h2(e[0], e[1], s1.x, s2.x);
                 dm_split_h2(e[2], e[3], s1.y, s2.y);
                 dm_split_h2(e[4], e[5], s1.z, s2.z);
@@ -437,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
         if constexpr (KIND == 4) if ((tap & 3) == 3) {
           // one output parity is complete: registers -> HBM (the input tile stays in LDS for the next parity)
           par = tap >> 2; py = par >> 1; px = par & 1;
-          if constexpr (SW) x6_epilogue_sw<MB, 4>(p, acc, reinterpret_cast<float*>(tile + NS * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, oscale);
+          if constexpr (SW) x6_epilogue_sw<MB, 4>(p, acc, reinterpret_cast<float*>(tile + NS * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, oscale * ainv);
           else conv_epilogue<MB, 4>(p, acc, reinterpret_cast<float*>(tile + NS * PL), nullptr, par, py, px, img0, tin, y0, x0,
                                     wm, wn, lane, h, tid, wave, bias_lane, true);
 #pragma unroll
@@ -451,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_kernel(const ConvArgs p) {
     if constexpr (KIND != 4) {
       __builtin_amdgcn_s_setprio(DM_PRIO_STAGE);
       if constexpr (SW) {  // registers -> HBM; the reduction words sit behind the planes (no overlay, no barrier)
-        x6_epilogue_sw<MB, KIND>(p, acc, reinterpret_cast<float*>(tile + NS * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, oscale);
+        x6_epilogue_sw<MB, KIND>(p, acc, reinterpret_cast<float*>(tile + NS * PL), par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, oscale * ainv);
       } else {
         __syncthreads();  // every wave is done reading the input tile: LDS is reused from here
         conv_epilogue<MB, KIND>(p, acc, smem + MT * 68, smem, par, py, px, img0, tin, y0, x0, wm, wn, lane, h, tid, wave, bias_lane, true);

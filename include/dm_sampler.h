@@ -231,7 +231,14 @@ int dm_unet_profile(dm_unet* m, const float* packed_dev, float* x_dev, const int
  * 10 / 11 / 12 = kinds 0 / 1 / 2 on the any-geometry kernel (gconv_kernel: any H, W; cin % 8 == 0; any cout; no fused
  * GroupNorm transform or statistics - see dm_groupnorm_silu): what dm_unet_forward uses whenever the image sides are
  * not powers of two or model_channels is outside {64,128,256,512} (model.py:72-73,120-151 accept any H, W % 8 == 0 and
- * any C % 8 == 0). */
+ * any C % 8 == 0),
+ * 13 / 14 / 15 = kinds 1 / 2 / 0 on the bf16-rate matrix pipe with every operand as TWO fp16 terms (three
+ * v_mfma_f32_32x32x16_f16 per product, fp32 accumulation; packed weights: two fp16 planes scaled by a power of two and the
+ * float that undoes it): as exact as kinds 7-9 for operands of order 1, which is what a GroupNorm in front guarantees - so
+ * these kinds need the fused GroupNorm transform (stats_in_dev), or, kind 15 only, raw inputs together with their producers'
+ * maxima (dm_debug_conv_amax) from which the image's power-of-two scale is taken; tiles of one image (>= 64 output pixels).
+ * What dm_unet_forward uses by default for its stride-2 / transposed convolutions, every conv2, and every conv1 whose
+ * producers wrote their maxima (DM_X6 bits 5, 6, 8). */
 size_t dm_conv_packed_floats(int kind, int cin, int cout);
 int dm_pack_conv_weight(int kind, const float* w_dev, int cin, int cout, float* packed_dev,
                         void* stream);
@@ -263,6 +270,11 @@ int dm_final_conv(const float* u_dev, const float* stats_dev, int pin, float cnt
  * in LDS: model.py:140,143,146): while taps_dev != NULL every later forward that takes that kernel also writes them, raw
  * fp32 NHWC, to taps_dev[B][6144] = down3 [4,4,64] | bottleneck [4,4,64] | up1 [8,8,64].  NULL switches it off. */
 void dm_debug_lowres_taps(float* taps_dev);
+/* Test hook: maxima buffers of the NEXT dm_conv2d call (kinds 7-9, 13-15, tiles of one image), cleared by that call.
+ * amax_out_dev: NULL or [B][dm_conv_stats_partials(kind, H, W) * (cout / 64) * 4] - the call writes the per-wave maxima of
+ * |y| there.  amax1_dev / amax2_dev ([B][namax1], [B][namax2]): kind 15 without stats_in_dev reads the maxima of its raw
+ * inputs x1 / x2 from them (any partition of the image into partial maxima). */
+void dm_debug_conv_amax(const float* amax1_dev, int namax1, const float* amax2_dev, int namax2, float* amax_out_dev);
 int dm_conv2d(int kind, const float* x1_dev, int c1, const float* x2_dev, int c2,
               const float* packed_w_dev, const float* bias_dev, int cout,
               const float* stats_in_dev, int pin, float cnt_in, const float* gamma_dev,

@@ -183,7 +183,7 @@ def test_fp16_form_weight_scaling(scale):
 
 def test_x6_model_forward_matches_fp32_mfma_forward_and_oracle(monkeypatch):
     """UNetMini.forward (model.py:120-151) with the 4x4 convolutions on the bf16 pipe (three-way bf16 split, DM_X6=7; the
-    default DM_X6=231 takes two fp16 terms: stride-2 / transposed convs and every conv2 behind a GroupNorm, and all twelve
+    default DM_X6=487 takes two fp16 terms: stride-2 / transposed convs and every conv2 behind a GroupNorm, and all twelve
     layers of the fused low-resolution kernel) against the same weights on the fp32-MFMA
     kernels only (DM_X6=0) and against the CPU oracle: the split forms move eps by less than the fp32 kernels' own distance
     from the oracle."""
@@ -197,7 +197,7 @@ def test_x6_model_forward_matches_fp32_mfma_forward_and_oracle(monkeypatch):
     m7 = d.UNetMini(image_size=32).eval()
     m7._native()
     m7.load_state_dict(m0.state_dict())
-    monkeypatch.setenv("DM_X6", "231")
+    monkeypatch.setenv("DM_X6", "487")
     m39 = d.UNetMini(image_size=32).eval()
     m39._native()
     m39.load_state_dict(m0.state_dict())
@@ -240,3 +240,47 @@ def test_init5_composed_first_layers_match_two_layer_form_and_oracle(monkeypatch
     assert not torch.equal(e0, e1)                        # (two different evaluations did run)
     assert (e0 - e1).abs().max().item() <= 2e-5
     assert (e1 - ref).abs().max().item() <= 1e-4 and (e0 - ref).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("H,c2,mag", [(32, 0, 1.0), (16, 64, 1.0), (8, 0, 1.0), (16, 64, 1e-4), (16, 0, 3e4), (64, 0, 7.0)])
+def test_fp16_form_on_raw_inputs_scaled_by_their_maxima(H, c2, mag):
+    """kind 15 without a GroupNorm in front (a block's conv1, model.py:54: its inputs are raw conv outputs): the image is scaled
+    by a power of two taken from its producers' maxima before it is split into two fp16 terms, so tiny and large activations
+    keep the accuracy of the fp32 kernels.  The maxima come from a producer launch (kind 14 writes them for its output) or,
+    here for the skip input, from any partition of the image into partial maxima."""
+    L = _lib.lib()
+    torch.manual_seed(H + c2)
+    B = 3
+    x1 = torch.randn(B, 64, H, H) * mag
+    x1[1] *= 37.0                                # images of one batch at different scales
+    x2 = torch.randn(B, c2, H, H) * mag * 0.1 if c2 else None
+    am1 = x1.abs().amax(dim=(1, 3)).contiguous().to(DEV)          # [B][H] partial maxima (rows)
+    am2 = None if x2 is None else x2.abs().amax(dim=(1, 2, 3)).reshape(B, 1).contiguous().to(DEV)
+    w, b = torch.randn(64, 64 + c2, 3, 3) * 0.05, torch.randn(64) * mag
+    L.dm_debug_conv_amax(_lib.ptr(am1), H, _lib.ptr(am2), 1 if c2 else 0, None)
+    y, st = run_x6(15, x1, x2, w, b)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1)
+    for i in range(B):   # per image: each has its own scale
+        assert (y[i].double() - ref[i]).abs().max().item() <= 2e-5 * ref[i].abs().max().item(), i
+    if mag == 1.0:
+        check_stats(st, ref.float(), B)
+
+
+def test_x6_kernels_write_the_maxima_of_their_output():
+    """amax_out of the stride-2 (pipelined kernel, both tile sizes) and transposed convolutions: the maximum over an image's
+    partial maxima equals max |y| of that image, exactly."""
+    L = _lib.lib()
+    torch.manual_seed(21)
+    for kind, B, H in ((13, 3, 32), (13, 300, 32), (14, 3, 16), (8, 2, 32), (9, 2, 16)):
+        h_raw = torch.randn(B, 64, H, H)
+        hg = h_raw.reshape(B, 8, -1)
+        mean = hg.mean(2)
+        st0 = torch.stack([mean, ((hg - mean[:, :, None]) ** 2).sum(2)], dim=-1).reshape(B, 1, 8, 2)
+        tf = (st0.to(DEV), 1, float(H * H * 8), torch.ones(64, device=DEV), torch.zeros(64, device=DEV), torch.zeros(1, 64, device=DEV), 0)
+        w, b = torch.randn(64, 64, 4, 4) * 0.05, torch.randn(64)
+        n = L.dm_conv_stats_partials(kind, H, H) * 4
+        am = torch.full((B, n), float("nan"), device=DEV)
+        L.dm_debug_conv_amax(None, 0, None, 0, _lib.ptr(am))
+        y, _ = run_x6(kind, h_raw, None, w, b, tf=tf, want_stats=False)
+        assert torch.equal(am.cpu().amax(1), y.abs().amax(dim=(1, 2, 3))), kind

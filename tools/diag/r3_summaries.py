@@ -32,6 +32,37 @@ def short(k):
     return k.split("(")[0].replace("void ", "").strip()
 
 
+def cls_of(k):
+    """bench.py's kernel-class name (K_NAMES) of a kernel."""
+    import re
+    if k.startswith("conv_mfma_kernel<2, 5"): return "conv3x3_winograd_mfma"
+    if re.match(r"conv_x6_kernel<\d, 0", k) or k.startswith("conv_x6_c3_kernel"): return "conv3x3_split16_mfma"
+    if re.match(r"conv_x6_kernel<\d, 1", k) or k.startswith("conv_x6_down_kernel"): return "conv4x4s2_split16_mfma"
+    if re.match(r"conv_x6_kernel<\d, [24]", k): return "convT4x4s2_split16_mfma"
+    if k.startswith("lowres_fused_kernel"): return "lowres_fused_split16_mfma"
+    if k.startswith("init5_kernel"): return "init_conv"
+    if k.startswith("final_conv"): return "final_conv"
+    return None
+
+
+def by_class(per, wkey, vkeys):
+    """launch-weighted class figures from per-kernel ones"""
+    out = {}
+    for k, e in per.items():
+        c = cls_of(k)
+        if c is None:
+            continue
+        o = out.setdefault(c, {"launches": 0, "kernels": []})
+        for v in vkeys:
+            o[v] = o.get(v, 0.0) + e[v] * e[wkey]
+        o["launches"] += e[wkey]
+        o["kernels"].append(k)
+    for o in out.values():
+        for v in vkeys:
+            o[v] /= o["launches"]
+    return out
+
+
 keys = set()
 
 # ---- kernel-trace --stats passes: the CSV as rocprofv3 wrote it + the bench line of the same command
@@ -51,17 +82,16 @@ for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
     if sum(v) < 50.0:
         continue
     summary[k] = {"launches": len(v), "avg_us": sum(v) / len(v), "total_ms": sum(v) / 1e3, "min_us": min(v), "max_us": max(v)}
-wino = [k for k in per if k.startswith("conv_mfma_kernel<2, 5, 64")]
-wl = [x for k in wino for x in per[k]]
+classes = by_class(summary, "launches", ["avg_us"])
 cfg2 = bench_line("prof_cfg2.json")
+dom = cfg2["roofline"]["class"]
 out = {"source": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs "
                  "(tools/diag/r3_profiles.sh stats; DDIM-50, B=1024, fp32): per-kernel durations from the kernel trace, every launch of "
                  "the run (warm-up, timed passes and bench.py's per-class profiling pass)",
-       "build_key": cfg2["build_key"], "winograd_class": wino, "winograd_class_launches": len(wl),
-       "winograd_class_avg_us": sum(wl) / len(wl), "bench_line_avg_launch_us_same_run": cfg2["roofline"]["avg_launch_us"],
-       "per_kernel": summary}
+       "build_key": cfg2["build_key"], "dominant_class": dom, "bench_line_avg_launch_us_same_run": cfg2["roofline"]["avg_launch_us"],
+       "classes": classes, "per_kernel": summary}
 json.dump(out, open(os.path.join(DST, "r3_rocprof_summary.json"), "w"), indent=1)
-print("winograd class: %d launches, %.1f us (bench line of the same run: %.1f us)" % (len(wl), out["winograd_class_avg_us"], cfg2["roofline"]["avg_launch_us"]))
+print("dominant class %s: %d launches, %.1f us by rocprof (bench line of the same run: %.1f us)" % (dom, classes[dom]["launches"], classes[dom]["avg_us"], cfg2["roofline"]["avg_launch_us"]))
 
 # ---- HBM traffic (two PMC passes)
 def load(path, name):
@@ -84,17 +114,14 @@ for k in sorted(f):
     wr = 1024 * sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
     tper[k] = {"launches": len(f[k]), "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
     print(f"{k:44s} {len(f[k]):5d}  read {rd/1e6:8.1f} MB  write {wr/1e6:8.1f} MB")
-twino = [k for k in tper if k.startswith("conv_mfma_kernel<2, 5, 64")]
-n = sum(tper[k]["launches"] for k in twino)
-rd = sum(tper[k]["hbm_read_bytes_per_launch"] * tper[k]["launches"] for k in twino) / n
-wr = sum(tper[k]["hbm_write_bytes_per_launch"] * tper[k]["launches"] for k in twino) / n
+tcls = by_class(tper, "launches", ["hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_bytes_per_launch"])
 json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs: tools/diag/r3_profiles.sh traffic) -- python3 "
                      "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-configs (DDIM-50, B=1024, fp32); FETCH_SIZE doubled "
-                     "(gfx950 tallies 128-B requests as 64 B), KiB -> bytes; launch-weighted over the Winograd class (the 32x32 and 16x16 layers)",
-           "build_key": bench_line("pmc_fetch.json")["build_key"], "kernel": "conv_mfma_kernel<2,5,64,*>", "launches": n,
-           "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr, "per_kernel": tper},
+                     "(gfx950 tallies 128-B requests as 64 B), KiB -> bytes; `classes`: launch-weighted per kernel class of bench.py",
+           "build_key": bench_line("pmc_fetch.json")["build_key"], "classes": tcls, "per_kernel": tper},
           open(os.path.join(DST, "r3_traffic.json"), "w"), indent=1)
-print("wino class:", n, "launches", rd / 1e6, "MB read", wr / 1e6, "MB written per launch")
+for c, o in tcls.items():
+    print(f"class {c:28s} {o['launches']:5d} launches  {o['hbm_read_bytes_per_launch']/1e6:8.1f} MB read {o['hbm_write_bytes_per_launch']/1e6:8.1f} MB written per launch")
 
 # ---- SQ counters per kernel (MFMA-busy share of SIMD cycles, vector instructions per MFMA)
 for tag in ("model", "cfg1"):
