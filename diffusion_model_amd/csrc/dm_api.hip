@@ -6,6 +6,7 @@
 #include "dm_kernels_bf16.hip"
 #include "dm_kernels_x6.hip"
 #include "dm_kernels_x6p.hip"
+#include "dm_kernels_x6c3.hip"
 #include "dm_kernels_init5.hip"
 #include "dm_kernels_generic.hip"
 #include "dm_kernels_lowres.hip"
@@ -234,6 +235,22 @@ int launch_conv_x6_down_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t 
   return 0;
 }
 
+template <bool TF, int HL>
+int launch_conv_x6_c3_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_done[DM_MAX_DEVICES] = {false};
+  const int dev = current_device();
+  if (!attr_done[dev]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_c3_kernel<TF, HL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done[dev] = true;
+  }
+  const double pix = (double)a.B * a.H * a.W;
+  const int cin = a.C1 + a.C2;
+  ProfScope ps(DM_K_X6_CONV3, s, 2.0 * pix * a.Cout * 9.0 * cin, 4.0 * pix * (cin + a.Cout) + 4.0 * 9.0 * cin * a.Cout);
+  hipLaunchKernelGGL((conv_x6_c3_kernel<TF, HL>), grid, dim3(256), lds, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // The fp32 convolutions on the bf16 matrix pipe (three-way split operands, conv_x6_kernel).  Same tile
 // decomposition (hence the same GroupNorm partial counts) as the other arithmetic variants.
 int launch_conv_x6(const ConvCall& c, hipStream_t s) {
@@ -308,6 +325,26 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
                                : (c.stats_in ? launch_conv_x6_down_t<MB_, 3, true>(a, gridp, lds_p, s) : launch_conv_x6_down_t<MB_, 3, false>(a, gridp, lds_p, s)))
     return g.MT == 128 ? DM_X6P(2) : DM_X6P(1);
 #undef DM_X6P
+  }
+  // 3x3, two fp16 terms, 8x16-pixel tiles of one image: the kernel with its staging pipelined into the K loop (dm_kernels_x6c3.hip)
+  static const bool x6_c3 = getenv("DM_DEBUG_X6_NOC3") == nullptr;  // (diagnostics: conv_x6_kernel instead)
+  if (x6_c3 && f16 && kind == 0 && g.MT == 128 && g.th_log == 3 && g.tw_log == 4 && c.c1 <= 256 && !x6_nopipe &&
+      c.H == c.W && c.H >= 16 && c.H <= 128 && (!c.c2 || c.c2 == c.c1) &&
+      (c.stats_in ? c.pin <= 8 : (c.namax1 <= 64 && c.namax2 <= 64))) {
+    const size_t lds_c = ((c.stats_in ? (size_t)6 * c.c1 : 0) + 64) * sizeof(float) + (size_t)2 * 2 * 180 * 40 * 2;
+    dim3 gridc((unsigned)(c.B * g.tiles_per_img), (unsigned)(c.cout / 64), 1u);
+    a.ntiles = (int)gridc.x;
+    const unsigned slots = 2u * cu_count(current_device());
+    const unsigned resident = slots / gridc.y ? slots / gridc.y : 1u;
+    if (gridc.x > resident) gridc.x = resident;
+    a.ngroups = c.B;
+    a.xcd_map = (gridc.x % 8 == 0 && gridc.y == 1 && c.B >= 64) ? 1 : 0;
+#ifdef DM_STAMPS
+    a.stamps = g_stamps;
+#endif
+#define DM_C3(HL_) (c.stats_in ? launch_conv_x6_c3_t<true, HL_>(a, gridc, lds_c, s) : launch_conv_x6_c3_t<false, HL_>(a, gridc, lds_c, s))
+    return c.H == 16 ? DM_C3(4) : c.H == 32 ? DM_C3(5) : c.H == 64 ? DM_C3(6) : DM_C3(7);
+#undef DM_C3
   }
   const int groups = (c.B + g.ni - 1) / g.ni;
   dim3 grid((unsigned)(groups * g.tiles_per_img), (unsigned)(c.cout / 64), (kind == 2 && !fused_up) ? 4u : 1u);

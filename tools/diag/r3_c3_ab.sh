@@ -1,8 +1,6 @@
-# A/B of the 3x3 two-fp16-term conv: staging pipelined into the K loop (conv_x6_c3_kernel, default) vs conv_x6_kernel (DM_DEBUG_X6_NOPIPE=1:
-# also switches the stride-2 conv back)
+# the 3x3 two-fp16-term conv with its staging pipelined into the K loop (conv_x6_c3_kernel, default) vs conv_x6_kernel (DM_DEBUG_X6_NOC3=1)
 for v in 0 1; do
-  for B in 1024; do
-    if [ $v = 1 ]; then export DM_DEBUG_X6_NOPIPE=1; else unset DM_DEBUG_X6_NOPIPE; fi
+    if [ $v = 1 ]; then export DM_DEBUG_X6_NOC3=1; else unset DM_DEBUG_X6_NOC3; fi
     timeout -k 10 100 python - <<PY || exit 1
 import torch, sys
 sys.path.insert(0, '.')
@@ -10,8 +8,7 @@ import bench
 import diffusion_model_amd as d
 d.set_seed(1)
 m = d.UNetMini(image_size=32).eval()
-per, raw = bench.profile_model(m, d.DDPMScheduler(), $B, 32, 32, reps=10)
-print("nopipe=$v B=$B", {k: (v["launches"], round(v["avg_us"], 1)) for k, v in per.items() if "split16" in k or "wino" in k}, "total", round(sum(v["avg_us"] * v["launches"] for v in per.values()), 1))
+per, raw = bench.profile_model(m, d.DDPMScheduler(), 1024, 32, 32, reps=10)
+print("noc3=$v", {k: (v["launches"], round(v["avg_us"], 1)) for k, v in per.items() if "split16" in k or "wino" in k}, "total", round(sum(v["avg_us"] * v["launches"] for v in per.values()), 1))
 PY
-  done
 done

@@ -12,8 +12,8 @@ kind, H, B = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 tf = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 stats = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 x1 = torch.randn(B, H, H, 64, device=dev)
-ks = 3 if kind in (0, 5, 7) else 4
-OH = H // 2 if kind in (1, 6, 8) else 2 * H if kind in (2, 4, 9) else H
+ks = 3 if kind in (0, 5, 7, 15) else 4
+OH = H // 2 if kind in (1, 6, 8, 13) else 2 * H if kind in (2, 4, 9, 14) else H
 w = torch.randn(64, 64, ks, ks, device=dev) * 0.05
 if os.environ.get("DM_TL_ZERO"):  # all-zero operands: how much of the time is switching power (clock) rather than issue slots?
     x1.zero_(); w.zero_()
