@@ -192,13 +192,19 @@ __global__ __launch_bounds__(256, 2) void conv_x6_down_kernel(const ConvArgs p) 
   };
 
   f32x16 acc[MB];
-  uint4 bq[2][NS];   // weight fragments of the upcoming (tap, j)
+  // weight fragments of the upcoming taps, [tap buffer][j][plane].  WD = taps of look-ahead: with two planes (three MFMAs per product)
+  // a (tap, j) group is six MFMAs and one tap ahead (12 MFMAs) does not cover an L2 hit - two taps ahead (24 MFMAs) do
+  constexpr int WD = (NS == 2) ? 2 : 1;
+  uint4 bq[WD][2][NS];
   {
     const unsigned w0p = wtap(0, 0);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int s = 0; s < NS; ++s) bq[j][s] = wload(w0p + s * split_off + j * jstride);
+      for (int s = 0; s < NS; ++s) {
+        bq[0][j][s] = wload(w0p + s * split_off + j * jstride);
+        if (WD == 2) bq[WD - 1][j][s] = wload(wtap(0, 1) + s * split_off + j * jstride);
+      }
   }
 
   // K loop of chunk q on buffer PB (compile-time) while chunk q + 1 is staged from R into the other buffer
@@ -228,16 +234,18 @@ __global__ __launch_bounds__(256, 2) void conv_x6_down_kernel(const ConvArgs p) 
     for (int tp = 0; tp < 4; ++tp) {
       const int tapoff = ((tp >> 1) * htw + (tp & 1)) * RSB;
       const int ntapoff = (((tp + 1) >> 1) * htw + ((tp + 1) & 1)) * RSB;
-      const unsigned wnext = (tp < 3) ? wtap(q, tp + 1) : wtap(q + 1 < nchunks ? q + 1 : 0, 0);
+      const int qn_ = q + 1 < nchunks ? q + 1 : 0;
+      const unsigned wnext = (tp + WD < 4) ? wtap(q, tp + WD) : wtap(qn_, tp + WD - 4);
+      const int tb = (WD == 2) ? (tp & 1) : 0;   // (four taps per chunk: the buffer parity is the tap's)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         uint4 (*acur)[MB] = ((tp * 2 + j) & 1) ? a1 : a0;
         uint4 (*anxt)[MB] = ((tp * 2 + j) & 1) ? a0 : a1;
         const bool more = !(tp == 3 && j == 1);
         const int noff = (j == 0) ? tapoff + 16 : ntapoff;
-        const uint4 b1 = bq[j][0];
-        const uint4 b2 = bq[j][1];
-        const uint4 b3 = bq[j][NS - 1];
+        const uint4 b1 = bq[tb][j][0];
+        const uint4 b2 = bq[tb][j][1];
+        const uint4 b3 = bq[tb][j][NS - 1];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NTERM; ++t) {
@@ -248,12 +256,12 @@ __global__ __launch_bounds__(256, 2) void conv_x6_down_kernel(const ConvArgs p) 
             acc[mb] = dm_mfma16<F16>(bv, acur[as][mb], acc[mb]);
             if (t < NS && more) anxt[t][mb] = *reinterpret_cast<const uint4*>(kb + ap[t][mb] + noff);
             if (NS == 3) {
-              if (t == 3 && mb == 0) bq[j][2] = wload(wnext + 2 * split_off + j * jstride);
-              if (t == 4 && mb == 0) bq[j][1] = wload(wnext + split_off + j * jstride);
+              if (t == 3 && mb == 0) bq[tb][j][2] = wload(wnext + 2 * split_off + j * jstride);
+              if (t == 4 && mb == 0) bq[tb][j][1] = wload(wnext + split_off + j * jstride);
             } else {
-              if (t == 1 && mb == MB - 1) bq[j][1] = wload(wnext + split_off + j * jstride);
+              if (t == 1 && mb == MB - 1) bq[tb][j][1] = wload(wnext + split_off + j * jstride);
             }
-            if (t == NTERM - 1 && mb == MB - 1) bq[j][0] = wload(wnext + j * jstride);
+            if (t == NTERM - 1 && mb == MB - 1) bq[tb][j][0] = wload(wnext + j * jstride);
             // the staging steps that ride behind this MFMA
             constexpr int TOT = U * NSTEP;
             const int i = ((tp * 2 + j) * NTERM + t) * MB + mb;
