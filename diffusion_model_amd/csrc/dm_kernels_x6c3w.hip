@@ -1,43 +1,150 @@
-// dm_kernels_x6c3.hip — conv_x6_c3_kernel: Conv2d 3x3 pad 1 (model.py:42,45,47) on 8x16-pixel tiles with every operand as two
-// fp16 terms (three v_mfma_f32_32x32x16_f16 per product, dm_kernels_x6.hip) and its STAGING SOFTWARE-PIPELINED INTO THE K LOOP:
-// the wave that issues the MFMAs of K chunk g of the chunk stream also transforms, splits and writes chunk g+1 into the other
-// half of a double-buffered LDS tile, a few vector instructions behind each MFMA (they ride in the matrix pipe's shadow), and
-// issues the global loads of chunk g+3.  In conv_x6_kernel the staging of one workgroup runs beside the K loop of the other
-// workgroup of its CU and is starved by it (an MFMA stream starves the vector instructions of the OTHER
-// waves of its SIMD, its own cost it almost nothing): 16.6 k of the 36 k cycles of a tile.
-//
-// A tile has only Cin/32 = 2 chunks (4 with the channel concat), so the stream runs ACROSS tiles: the next tile's first chunk
-// is staged under this tile's last K loop, its loads were issued one tile earlier, and what that staging needs of the next
-// image - the GroupNorm tables (TF: conv2 reads SiLU(GroupNorm(conv1)) + temb) or the power-of-two scale from the producers'
-// maxima (!TF: conv1 reads its inputs raw) - is fetched at the start of the K loop before and finished at its end.
-//   chunk  = 32 input channels of the 10x18 halo tile, 9 taps x 2 x 16 channels, 108 MFMAs per wave
-//   LDS    = 2 x GroupNorm tables | reduction words | 2 buffers x 2 planes x [halo pixel][32 + 8] fp16   (57.6 KB + tables)
-// The K loop is kept lean in scalar registers and vector instructions (readlane/writelane traffic of spilled scalars cost the
-// first version 3 vector instructions per MFMA): image side HL = log2(H) = log2(W) at compile time, one scalar descriptor per
-// loaded chunk (base pointer, byte offsets of the tile's halo origin and of its first pixel, border flags), per-piece constants
-// (byte offset inside the halo, border code) in one vector register each, weight addresses as a scalar pointer per tap plus
-// four fixed lane offsets.
+// dm_kernels_x6c3w.hip — conv_x6_c3w_kernel: conv_x6_c3_kernel (dm_kernels_x6c3.hip: Conv2d 3x3 pad 1, model.py:42,45,47, two
+// fp16 terms per operand, staging pipelined into the K loop across tiles) with a WIDER REGISTER TILE PER WAVE: a workgroup is
+// two waves, each computing 64 pixels x all 64 output channels of the tile (two pixel blocks x two channel blocks of 32x32
+// accumulators) instead of four waves of 64 pixels x 32 channels.  Per (tap, 16-channel) group a wave then issues twelve MFMAs on
+// four pixel fragments (LDS) and four weight fragments (L1/L2) where conv_x6_c3_kernel issues six on four and two: half the LDS
+// reads per MFMA.  The chip runs these kernels at its power limit (profiles/r3_diag_c3_operand_streams.log: leaving the LDS
+// re-reads out speeds up every kernel of the step, not only this one), so operand traffic is paid twice, in issue slots and in
+// clock.  One wave per SIMD (two workgroups per CU, 512 registers per lane: accumulators in the AGPR half): the wave's own
+// staging and loads ride behind its MFMAs as before, nothing else competes for its SIMD.  Same K order and output arithmetic as
+// conv_x6_c3_kernel (bit-identical outputs and maxima; the GroupNorm partials are summed in another order).
 #pragma once
-#include "dm_kernels_x6.hip"
+#include "dm_kernels_x6c3.hip"
+#ifndef DM_C3W_EXP
+#define DM_C3W_EXP 0   // timing experiments (tools/diag/r3_c3w_exp.sh; wrong results): bit 0 = no stores, 1 = no statistics,
+#endif                 // 2 = no staging in the K loop, 3 = pixel fragments read once per chunk, 4 = weight fragments loaded once,
+                       // 5 = staging without the SiLU, 6 = staging without the fp16 split
 
-// compile-time loop: f(integral_constant<int, 0>{}) ... f(integral_constant<int, N - 1>{}) (the unroller gives up on bodies this size)
-template <class F, size_t... I>
-__device__ __forceinline__ void dm_static_for_impl(F&& f, std::index_sequence<I...>) { (f(std::integral_constant<int, (int)I>{}), ...); }
-#ifndef DM_C3_EXP
-#define DM_C3_EXP 0
-#endif
-template <int N, class F>
-__device__ __forceinline__ void dm_static_for(F&& f) { dm_static_for_impl(f, std::make_index_sequence<N>{}); }
+// x6_epilogue_sw (dm_kernels_x6.hip) for a wave that holds NB channel blocks of its pixels: two waves (wm = 0, 1) per tile; the
+// (wave, channel block) pair takes the place of x6_epilogue_sw's wave wm * 2 + wn in the layout of the maxima.  Outputs and
+// maxima are the same bits as conv_x6_c3_kernel's; the GroupNorm partials are summed in another order.  3x3 only (no parities).
+template <int MB, int NB>
+__device__ __forceinline__ void x6_epilogue_wide(const ConvArgs& p, f32x16 (&acc)[MB][NB], float* scr, int img0, int tin, int y0, int x0,
+                                                 int wm, int lane, int h, int tid, float oscale) {
+  static_assert(NB == 2, "two channel blocks of 32 = the 64 channels of blockIdx.y");
+  constexpr int MT = 64 * MB;
+  const int cb0 = blockIdx.y * 64 + 4 * h;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.bias + cb0 + nb * 32 + 8 * k);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        acc[mb][nb][4 * k] = fmaf(acc[mb][nb][4 * k], oscale, bv.x); acc[mb][nb][4 * k + 1] = fmaf(acc[mb][nb][4 * k + 1], oscale, bv.y);
+        acc[mb][nb][4 * k + 2] = fmaf(acc[mb][nb][4 * k + 2], oscale, bv.z); acc[mb][nb][4 * k + 3] = fmaf(acc[mb][nb][4 * k + 3], oscale, bv.w);
+      }
+    }
+  if (p.amax_out) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      float mx = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[mb][nb][r]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      if (lane == 0) p.amax_out[(((size_t)img0 * p.pout + tin) * gridDim.y + blockIdx.y) * 4 + wm * 2 + nb] = mx;
+    }
+  }
+  if (p.stats_out && !(DM_C3W_EXP & 2)) {
+    // (mean, M2) of the tile's 128 pixels per group, two passes.  A wave holds eight runs of eight channels (run r = nb * 4 + k:
+    // channels 8r .. 8r + 7 over the lane halves); the eight per-lane sums are reduced over the 64 lanes in one halving
+    // butterfly (v_permlane32_swap, v_permlane16_swap, DPP: no LDS crossbar), after which lane l holds the total of run
+    // (l >> 3) & 7; the two waves' totals meet in LDS and thread g adds the runs of group g.
+    const int gpt = 64 >> p.g_log;            // groups in the workgroup's 64 channels
+    const int rpg_log = p.g_log - 3;          // log2(runs per group)
+    float* sredA = scr;                        // [wm][8 runs]
+    float* sredB = scr + 16;
+    float* s_mu = scr + 32;                    // [<= 8]
+    const float inv_cnt = 1.0f / (float)(MT << p.g_log);
+    for (int pass = 0; pass < 2; ++pass) {
+      float v[8];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float mu = pass ? s_mu[(nb * 4 + k) >> rpg_log] : 0.f;
+          float sm = 0.f;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = acc[mb][nb][4 * k + e] - mu;
+              sm += pass ? d * d : d;
+            }
+          v[nb * 4 + k] = sm;
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // lanes l, l ^ 32: the low half keeps runs 0..3, the high half runs 4..7
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[q]), __float_as_uint(v[q + 4]), false, false);
+        v[q] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {   // rows of 16 lanes: even rows keep runs q, odd rows runs q + 2
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[q]), __float_as_uint(v[q + 2]), false, false);
+        v[q] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+      const bool hi8 = (lane & 8) != 0;  // lanes l, l ^ 8 (row_ror:8): bit 3 clear keeps run 0 of the pair, set keeps run 1
+      const float keep = hi8 ? v[1] : v[0], send = hi8 ? v[0] : v[1];
+      float t = keep + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xF, 0xF, true));
+      t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+      t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+      t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xF, 0xF, true));  // row_half_mirror
+      float* sred = pass ? sredB : sredA;
+      if ((lane & 7) == 0) sred[wm * 8 + ((lane >> 3) & 7)] = t;
+      __syncthreads();
+      if (tid < gpt) {
+        float sm = 0.f;
+        for (int r = tid << rpg_log; r < (tid + 1) << rpg_log; ++r) sm += sred[r] + sred[8 + r];
+        if (pass == 0) s_mu[tid] = sm * inv_cnt;
+        else {
+          float* so = p.stats_out + (((size_t)img0 * p.pout + tin) * DM_GROUPS + blockIdx.y * gpt + tid) * 2;
+          so[0] = s_mu[tid];
+          so[1] = sm;
+        }
+      }
+      if (pass == 0) __syncthreads();
+    }
+  }
+  if (DM_C3W_EXP & 1) {
+    float t = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[mb][nb][r];
+    if (t == 123.456f) p.y[0] = t;
+    return;
+  }
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = wm * (32 * MB) + mb * 32 + (lane & 31);
+    const int x = x0 + (m & ((1 << p.tw_log) - 1)), y = y0 + (m >> p.tw_log);
+    float* q = p.y + ((((size_t)img0 * p.H + y) * p.W + x) << p.cout_log) + cb0;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<float4*>(q + nb * 32 + 8 * k) = make_float4(acc[mb][nb][4 * k], acc[mb][nb][4 * k + 1], acc[mb][nb][4 * k + 2], acc[mb][nb][4 * k + 3]);
+  }
+}
 
 template <bool TF, int HL>
-__global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
-  constexpr int MB = 2, NS = 2, KC = 32, RSB = KC + 8;
+__global__ __launch_bounds__(128, 1) void conv_x6_c3w_kernel(const ConvArgs p) {
+  constexpr int MB = 2, NB = 2, NS = 2, KC = 32, RSB = KC + 8, NT = 128;
   constexpr int H = 1 << HL, W = 1 << HL;                 // square power-of-two images (host-checked)
   constexpr int tw = 16, htw = tw + 2, hth = 10;          // tile = 8 x 16 output pixels, halo 10 x 18
   constexpr int NP = hth * htw, items = NP * 8;           // 1440 pieces of 4 channels per chunk
-  constexpr int U = 6;                                    // pieces per thread and chunk (1536 slots)
-  constexpr int NSTEP = 10;
-  constexpr int NMFMA = 9 * 2 * 3 * MB;                   // 108
+  constexpr int U = 12;                                   // pieces per thread and chunk (1536 slots)
+  constexpr int NSTEP = 9;
+  constexpr int NMFMA = 9 * 2 * 3 * MB * NB;              // 216
   constexpr int PL = NP * RSB, BUF = NS * PL;
   constexpr int TX_LOG = HL - 4, TPI_LOG = 2 * HL - 7;    // tiles per row / per image (logs)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -46,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
   if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 128] = 0;
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5;
+  const int wm = wave, h = lane >> 5;
   const int C1 = p.C1;
   const int cl2 = p.c1_log + 2;                 // log2 of a pixel's bytes (both inputs: C1 == C2, host-checked)
   float* tabs = smem;                           // tables [2 tile parities][scale | shift | temb][C1]
@@ -65,22 +172,21 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
   const int ldso0 = (tid >> 3) * RSB + (tid & 7) * 4;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int idx = u * 256 + tid;
+    const int idx = u * NT + tid;
     const int pix = idx >> 3;
     const int hy = pix / htw, hx = pix - hy * htw;
     const unsigned off = ((unsigned)(hy * W + hx) << cl2) + (unsigned)(tid & 7) * 16u;
     pcode[u] = (idx < items) ? (off | (hy == 0 ? 1u << 28 : 0u) | (hy == hth - 1 ? 1u << 29 : 0u) | (hx == 0 ? 1u << 30 : 0u) | (hx == htw - 1 ? 1u << 31 : 0u))
                              : (1u << 27);
   }
-  const int ldso_last = (pcode[U - 1] & (1u << 27)) ? KC : ldso0 + (U - 1) * 32 * RSB;   // (KC: the 8 unused fp16 behind a pixel's 32)
+  const int ldso_last = (pcode[U - 1] & (1u << 27)) ? KC : ldso0 + (U - 1) * (NT / 8) * RSB;   // (KC: the 8 unused fp16 behind a pixel's 32)
   const int c4o = (tid & 7) * 4;
 
   const int nchunks = (p.C1 + p.C2) >> 5;       // even: channel counts are multiples of 64
   const unsigned jstride = (unsigned)(p.Cout >> 5) * 1024u;         // bytes per (16 input channels, all output channels)
   const unsigned tapstride = (unsigned)((p.C1 + p.C2) >> 4) * jstride;
   const unsigned split_off = 9u * tapstride;
-  const int wn_s = __builtin_amdgcn_readfirstlane(wn);
-  const char* wcol = reinterpret_cast<const char*>(p.wp) + (size_t)(blockIdx.y * 2 + wn_s) * 1024;
+  const char* wcol = reinterpret_cast<const char*>(p.wp) + (size_t)(blockIdx.y * 2) * 1024;   // (+ 1024: the second channel block)
   unsigned wv[2][NS];   // lane offsets of the four fragments of a tap: [j][plane]
 #pragma unroll
   for (int j = 0; j < 2; ++j)
@@ -137,35 +243,35 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
       const float4 v = R[u];
       if (TF) { w0 = fmaf(v.x, tsc.x, tsh.x); w1 = fmaf(v.y, tsc.y, tsh.y); w2 = fmaf(v.z, tsc.z, tsh.z); w3 = fmaf(v.w, tsc.w, tsh.w); }
       else { w0 = v.x * sc_cur; w1 = v.y * sc_cur; w2 = v.z * sc_cur; w3 = v.w * sc_cur; }
+    } else if constexpr ((DM_C3W_EXP & 32) && s >= 1 && s <= 4) {
     } else if constexpr (s == 1) {
-      if (do_load) issue(R[u], msk, u, dl);
-    } else if constexpr (s == 2) {
       if (TF) { const dm_f2 a = dm_f2{w0, w1} * nl2e; ex = dm_f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
-    } else if constexpr (s == 3) {
+    } else if constexpr (s == 2) {
       if (TF) {
         const dm_f2 d = ex + one2;
         const dm_f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
         const dm_f2 o = __builtin_elementwise_fma(dm_f2{w0, w1}, r, dm_f2{tte.x, tte.y});
         w0 = o.x; w1 = o.y;
       }
-    } else if constexpr (s == 4) {
+    } else if constexpr (s == 3) {
       if (TF) { const dm_f2 a = dm_f2{w2, w3} * nl2e; ex = dm_f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
-    } else if constexpr (s == 5) {
+    } else if constexpr (s == 4) {
       if (TF) {
         const dm_f2 d = ex + one2;
         const dm_f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
         const dm_f2 o = __builtin_elementwise_fma(dm_f2{w2, w3}, r, dm_f2{tte.z, tte.w});
         w2 = o.x; w3 = o.y;
       }
-    } else if constexpr (s == 6) {  // zero padding stays exactly 0
+    } else if constexpr (s == 5) {  // zero padding stays exactly 0
       w0 = __uint_as_float(__float_as_uint(w0) & okm); w1 = __uint_as_float(__float_as_uint(w1) & okm);
       w2 = __uint_as_float(__float_as_uint(w2) & okm); w3 = __uint_as_float(__float_as_uint(w3) & okm);
-    } else if constexpr (s == 7) dm_split_h2(w0, w1, q1a, q2a);
-    else if constexpr (s == 8) dm_split_h2(w2, w3, q1b, q2b);
+    } else if constexpr ((DM_C3W_EXP & 64) && (s == 6 || s == 7)) { q1a = __float_as_uint(w0); q2a = __float_as_uint(w1); q1b = __float_as_uint(w2); q2b = __float_as_uint(w3);
+    } else if constexpr (s == 6) dm_split_h2(w0, w1, q1a, q2a);
+    else if constexpr (s == 7) dm_split_h2(w2, w3, q1b, q2b);
     else {
       // (no branch: behind a condition the compiler sinks the whole piece's arithmetic into the conditional block, one serial blob
       //  behind one MFMA; a piece past the halo - last u only - goes to the unused tail of pixel row 0)
-      bf16_t* q = dstb + (u == U - 1 ? ldso_last : ldso0 + u * 32 * RSB);
+      bf16_t* q = dstb + (u == U - 1 ? ldso_last : ldso0 + u * (NT / 8) * RSB);
       *reinterpret_cast<uint2*>(q) = make_uint2(q1a, q1b);
       *reinterpret_cast<uint2*>(q + PL) = make_uint2(q2a, q2b);
     }
@@ -235,16 +341,18 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
     }
   };
 
-  f32x16 acc[MB];
-  // weight fragments of the next TWO taps ([tap buffer][j][plane]): a fragment is requested four (tap, j) groups = 24 MFMAs before
-  // its first use (two groups of six MFMAs do not cover an L2 hit).  Nine taps per chunk: the buffer parity flips with the chunk.
-  uint4 bq[2][2][NS];
+  f32x16 acc[MB][NB];
+  // weight fragments of the next TWO taps ([tap buffer][j][channel block][plane]), a fragment requested 48 MFMAs before its first
+  // use.  Nine taps per chunk: the buffer parity flips with the chunk.
+  uint4 bq[2][2][NB][NS];
 #pragma unroll
   for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int s = 0; s < NS; ++s) bq[tb][j][s] = wload(wtap(0, tb), wv[j][s]);
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bq[tb][j][nb][s] = wload(wtap(0, tb), wv[j][s] + nb * 1024u);
 
   // K loop of chunk q (buffer PB = q & 1, compile time) while the stream's next chunk is staged from R into the other buffer;
   // dl: descriptor of the chunk whose loads refill R (do_load).  pre_ts >= 0: this K loop also prepares the tables / scale of the
@@ -268,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
     DM_TL(2);
     dm_static_for<NMFMA>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      constexpr int mb = i % MB, t = (i / MB) % 3, j = (i / (3 * MB)) % 2, tp = i / (6 * MB);
+      constexpr int mb = i % MB, nb = (i / MB) % NB, t = (i / (MB * NB)) % 3, j = (i / (3 * MB * NB)) % 2, tp = i / (6 * MB * NB);
       constexpr int tapoff = ((tp / 3) * htw + tp % 3) * RSB;
       constexpr int ntapoff = (((tp + 1) / 3) * htw + (tp + 1) % 3) * RSB;
       constexpr int tb = (tp + PB) & 1;       // tap buffer (PB: that of this chunk's tap 0)
@@ -278,24 +386,29 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
       constexpr int as = (t == 1) ? 1 : 0;    // products h1 g2, h2 g1, h1 g1
       uint4 (&acur)[NS][MB] = odd ? a1 : a0;
       uint4 (&anxt)[NS][MB] = odd ? a0 : a1;
-      if constexpr (t == 0 && mb == 0) __builtin_amdgcn_sched_barrier(0);
-      acc[mb] = dm_mfma16<true>(t == 0 ? bq[tb][j][1] : bq[tb][j][0], acur[as][mb], acc[mb]);
-#if !(DM_C3_EXP & 1)   // timing experiment (tools/diag/r3_c3_exp.sh; wrong results): bit 0 = no pixel-operand re-reads from LDS,
-      if constexpr (t < NS && more) anxt[t][mb] = *reinterpret_cast<const uint4*>(kb + ap[t][mb] + noff);
-#endif                 //                                                                  bit 1 = no weight-fragment loads in the K loop
-      if constexpr (!(DM_C3_EXP & 2) && mb == MB - 1 && (t == 1 || t == 2)) {
+      if constexpr (t == 0 && mb == 0 && nb == 0) __builtin_amdgcn_sched_barrier(0);
+      acc[mb][nb] = dm_mfma16<true>(t == 0 ? bq[tb][j][nb][1] : bq[tb][j][nb][0], acur[as][mb], acc[mb][nb]);
+      if constexpr (!(DM_C3W_EXP & 8) && t < NS && nb == 0 && more) anxt[t][mb] = *reinterpret_cast<const uint4*>(kb + ap[t][mb] + noff);
+      if constexpr (!(DM_C3W_EXP & 16) && mb == MB - 1 && (t == 0 || t == 2)) {
         const char* wnext = (tp < 7) ? wtap(q, tp + 2) : wtap(qn, tp - 7);   // two taps ahead (scalar)
-        if constexpr (t == 1) bq[tb][j][1] = wload(wnext, wv[j][1]);
-        else bq[tb][j][0] = wload(wnext, wv[j][0]);
+        if constexpr (t == 0) bq[tb][j][nb][1] = wload(wnext, wv[j][1] + nb * 1024u);
+        else bq[tb][j][nb][0] = wload(wnext, wv[j][0] + nb * 1024u);
       }
       constexpr int TOT = U * NSTEP;
       constexpr int k0 = i * TOT / NMFMA, k1 = (i + 1) * TOT / NMFMA;   // at most one staging step behind an MFMA (TOT <= NMFMA)
       static_assert(k1 - k0 <= 1, "one staging step per MFMA");
-      if constexpr (k1 > k0) {
+      if constexpr (!(DM_C3W_EXP & 4) && k1 > k0) {
         if (do_stage) stage_step(R, msk, std::integral_constant<int, k0 / NSTEP>{}, std::integral_constant<int, k0 % NSTEP>{}, sb, dl, do_load);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
+    // the refill of R in ONE batch behind the chunk's last staging step: loads return in order, so a wait for a weight fragment
+    // requested after a refill load also waits for that load (HBM latency); one batch per chunk is covered by the fragments'
+    // 48-MFMA lead, a refill load behind every piece was not (it stalled the wave twelve times per chunk)
+    if (!(DM_C3W_EXP & 4) && do_stage && do_load) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) issue(R[u], msk, u, dl);
+    }
     DM_TL(3);
     if (pre_ts >= 0) next_finish(ts_pre, sc_pre, inv_pre);
   };
@@ -323,6 +436,10 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
       constexpr int k = decltype(kc)::value;
       stage_step(RA, mA, std::integral_constant<int, k / NSTEP>{}, std::integral_constant<int, k % NSTEP>{}, tile, d2, two || h1);
     });
+    if (two || h1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) issue(RA[u], mA, u, d2);
+    }
   }
   __syncthreads();
 
@@ -332,7 +449,9 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 #pragma unroll 1
     for (int q = 0; q < nchunks; q += 2) {
       // stream positions relative to this tile: staged q + 1 (, q + 2), loaded q + 3 (, q + 4); tile = position / nchunks
@@ -362,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
     {
       const int t = tile_id(ts);
       const int img = t >> TPI_LOG, tin = t & ((1 << TPI_LOG) - 1);
-      x6_epilogue_sw<MB, 0>(p, acc, scr, 0, 0, 0, img, tin, (tin >> TX_LOG) << 3, (tin & ((1 << TX_LOG) - 1)) << 4, wm, wn, lane, h, tid, wave, wscale * inv0);
+      x6_epilogue_wide<MB, NB>(p, acc, scr, img, tin, (tin >> TX_LOG) << 3, (tin & ((1 << TX_LOG) - 1)) << 4, wm, lane, h, tid, wscale * inv0);
     }
     DM_TL(4);
     sc0 = sc1; inv0 = inv1;

@@ -2,7 +2,7 @@
 // three bf16 terms on the bf16 matrix pipe, dm_kernels_x6.hip) with its STAGING SOFTWARE-PIPELINED INTO THE K LOOP.
 //
 // Why (tools/diag/r3_filler.sh, profiles/r3_diag_filler.log): a bf16 MFMA occupies the matrix pipe for 32 cycles and its wave's
-// issue slot for 4; three more vector instructions of the SAME wave behind every MFMA cost the K loop 1.5 %, six cost 11 %.
+// issue slot for 4; three more vector instructions of the SAME wave behind every MFMA cost the kernel 3 %, six cost 12 %.
 // Vector work of ANOTHER wave of the SIMD is starved by an MFMA stream instead, so conv_x6_kernel's staging
 // phase (GroupNorm + SiLU + three-way split: ~11 vector instructions per element, 2.6 per MFMA) is paid in full while the
 // partner workgroup's K loop crawls around it.  Here the wave that issues the MFMAs of K chunk c also transforms, splits and

@@ -115,6 +115,27 @@ def test_x6_conv_fused_groupnorm_silu_temb(kind, H):
     check_stats(st, ref, B)
 
 
+@pytest.mark.parametrize("C,H", [(128, 16), (128, 32), (256, 16)])
+def test_fp16_3x3_wide_and_four_wave_kernels(C, H):
+    """3x3 in the two-fp16-term form behind a GroupNorm at the widened model's channel counts: C <= 128 runs conv_x6_c3w_kernel
+    (two waves of 64 pixels x 64 channels, four K chunks at C = 128), C = 256 conv_x6_c3_kernel (four waves, its tables are one
+    channel per thread); both against the fp32 reference, GroupNorm partials included (model.py:54-62)."""
+    torch.manual_seed(C + H)
+    B = 3
+    h_raw = torch.randn(B, C, H, H) * 1.5 - 0.5
+    hg = h_raw.reshape(B, 8, -1)
+    mean = hg.mean(2)
+    st0 = torch.stack([mean, ((hg - mean[:, :, None]) ** 2).sum(2)], dim=-1).reshape(B, 1, 8, 2)
+    gamma, beta, temb = torch.rand(C) + 0.5, torch.randn(C) * 0.1, torch.randn(1, C)
+    tf = (st0.to(DEV), 1, float(H * H * C // 8), gamma.to(DEV), beta.to(DEV), temb.to(DEV), 0)
+    w, b = torch.randn(C, C, 3, 3) * 0.03, torch.randn(C)
+    y, st = run_x6(15, h_raw, None, w, b, tf=tf)
+    hin = F.silu(F.group_norm(h_raw, 8, gamma, beta, eps=1e-5)) + temb[:, :, None, None]
+    ref = ref_conv(15, hin, w, b)
+    assert (y - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item())
+    check_stats(st, ref, B)
+
+
 def test_x6_split_keeps_fp32_accuracy_on_badly_scaled_inputs():
     """Operands spanning many binades (1e-6 .. 1e4): the three-term split carries 24 mantissa bits whatever the
     magnitude, so the result stays within fp32 rounding of the float64 convolution, relative to sum |x||w|."""

@@ -36,7 +36,7 @@ def cls_of(k):
     """bench.py's kernel-class name (K_NAMES) of a kernel."""
     import re
     if k.startswith("conv_mfma_kernel<2, 5"): return "conv3x3_winograd_mfma"
-    if re.match(r"conv_x6_kernel<\d, 0", k) or k.startswith("conv_x6_c3_kernel"): return "conv3x3_split16_mfma"
+    if re.match(r"conv_x6_kernel<\d, 0", k) or k.startswith("conv_x6_c3"): return "conv3x3_split16_mfma"
     if re.match(r"conv_x6_kernel<\d, 1", k) or k.startswith("conv_x6_down_kernel"): return "conv4x4s2_split16_mfma"
     if re.match(r"conv_x6_kernel<\d, [24]", k): return "convT4x4s2_split16_mfma"
     if k.startswith("lowres_fused_kernel"): return "lowres_fused_split16_mfma"
