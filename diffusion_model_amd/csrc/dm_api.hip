@@ -7,7 +7,6 @@
 #include "dm_kernels_x6.hip"
 #include "dm_kernels_x6p.hip"
 #include "dm_kernels_x6c3.hip"
-#include "dm_kernels_x6c3w.hip"
 #include "dm_kernels_init5.hip"
 #include "dm_kernels_generic.hip"
 #include "dm_kernels_lowres.hip"
@@ -252,22 +251,6 @@ int launch_conv_x6_c3_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s)
   return 0;
 }
 
-template <bool TF, int HL>
-int launch_conv_x6_c3w_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr_done[DM_MAX_DEVICES] = {false};
-  const int dev = current_device();
-  if (!attr_done[dev]) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_x6_c3w_kernel<TF, HL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done[dev] = true;
-  }
-  const double pix = (double)a.B * a.H * a.W;
-  const int cin = a.C1 + a.C2;
-  ProfScope ps(DM_K_X6_CONV3, s, 2.0 * pix * a.Cout * 9.0 * cin, 4.0 * pix * (cin + a.Cout) + 4.0 * 9.0 * cin * a.Cout);
-  hipLaunchKernelGGL((conv_x6_c3w_kernel<TF, HL>), grid, dim3(128), lds, s, a);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
 // The fp32 convolutions on the bf16 matrix pipe (three-way split operands, conv_x6_kernel).  Same tile
 // decomposition (hence the same GroupNorm partial counts) as the other arithmetic variants.
 int launch_conv_x6(const ConvCall& c, hipStream_t s) {
@@ -359,13 +342,6 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
 #ifdef DM_STAMPS
     a.stamps = g_stamps;
 #endif
-    // two waves of 64 pixels x 64 channels per tile (dm_kernels_x6c3w.hip: half the LDS reads per MFMA; its tables are one channel per thread)
-    static const bool x6_c3w = getenv("DM_DEBUG_X6_NOC3W") == nullptr;  // (diagnostics: the four-wave kernel instead; same bits)
-    if (x6_c3w && c.c1 <= 128) {
-#define DM_C3W(HL_) (c.stats_in ? launch_conv_x6_c3w_t<true, HL_>(a, gridc, lds_c, s) : launch_conv_x6_c3w_t<false, HL_>(a, gridc, lds_c, s))
-      return c.H == 16 ? DM_C3W(4) : c.H == 32 ? DM_C3W(5) : c.H == 64 ? DM_C3W(6) : DM_C3W(7);
-#undef DM_C3W
-    }
 #define DM_C3(HL_) (c.stats_in ? launch_conv_x6_c3_t<true, HL_>(a, gridc, lds_c, s) : launch_conv_x6_c3_t<false, HL_>(a, gridc, lds_c, s))
     return c.H == 16 ? DM_C3(4) : c.H == 32 ? DM_C3(5) : c.H == 64 ? DM_C3(6) : DM_C3(7);
 #undef DM_C3

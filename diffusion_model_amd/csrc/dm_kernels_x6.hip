@@ -115,19 +115,21 @@ __device__ __forceinline__ void x6_epilogue_sw(const ConvArgs& p, f32x16 (&acc)[
     if (lane == 0) p.amax_out[(((size_t)img0 * p.pout + pidx) * gridDim.y + blockIdx.y) * 4 + wave] = mx;
   }
   if (p.stats_out) {
-    // channels per group G = 8 .. 64; this wave's 32 channels hold 32/G groups (G = 64: half a group)
-    const int kg_log = p.g_log - 3 < 2 ? p.g_log - 3 : 2;  // log2(k runs per group inside the wave): 0, 1, 2
-    const int ngw = 4 >> kg_log;                           // group slots of this wave
-    const int gpt_log = 6 - p.g_log, gpt = 1 << gpt_log;   // groups in the workgroup's 64 channels
-    float* sredA = scr;        // [4 waves][4]
-    float* sredB = scr + 16;   // [4 waves][4]
+    // (mean, M2) of the tile's pixels per group, two passes.  A wave holds four runs of eight channels (run k: channels
+    // wn*32 + 8k .. + 7 over the lane halves); its four per-lane sums are reduced over the 64 lanes in one halving butterfly
+    // (v_permlane32_swap, v_permlane16_swap, DPP row sum: no LDS crossbar), after which the lanes of row r hold the total of
+    // run r; the waves' totals meet in LDS and thread g adds the runs of group g (G = 8 .. 64 channels: 1 .. 8 runs).
+    const int gpt = 64 >> p.g_log;            // groups in the workgroup's 64 channels
+    const int rpg_log = p.g_log - 3;          // log2(runs per group)
+    float* sredA = scr;        // [4 waves][4 runs]
+    float* sredB = scr + 16;
     float* s_mu = scr + 32;    // [<= 8]
     const float inv_cnt = 1.0f / (float)(MT << p.g_log);
     for (int pass = 0; pass < 2; ++pass) {
-      float val[4];
+      float v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float mu = pass ? s_mu[(wn * 4 + k) >> (p.g_log - 3)] : 0.f;
+        const float mu = pass ? s_mu[(wn * 4 + k) >> rpg_log] : 0.f;
         float sm = 0.f;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
@@ -136,30 +138,21 @@ __device__ __forceinline__ void x6_epilogue_sw(const ConvArgs& p, f32x16 (&acc)[
             const float d = acc[mb][4 * k + e] - mu;
             sm += pass ? d * d : d;
           }
-        val[k] = sm;
+        v[k] = sm;
       }
-      if (kg_log >= 1) { val[0] += val[1]; val[2] += val[3]; val[1] = val[2]; }
-      if (kg_log == 2) val[0] += val[1];
-      float* sred = pass ? sredB : sredA;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q < ngw) {
-          float v = val[q];
-          v += __shfl_xor(v, 32, 64);
-          v += __shfl_xor(v, 16, 64);
-          v = dm_row16_sum(v);  // (DPP row operations: no LDS crossbar for the last four steps)
-          if (lane == 0) sred[wave * 4 + q] = v;
-        }
+      for (int q = 0; q < 2; ++q) {   // lanes l, l ^ 32: the low half keeps runs 0, 1, the high half runs 2, 3
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[q]), __float_as_uint(v[q + 2]), false, false);
+        v[q] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
       }
+      const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);   // rows: even keep the first, odd the second
+      const float t = dm_row16_sum(__uint_as_float(r16[0]) + __uint_as_float(r16[1]));
+      float* sred = pass ? sredB : sredA;
+      if ((lane & 15) == 0) sred[wave * 4 + (lane >> 4)] = t;
       __syncthreads();
       if (tid < gpt) {
-        // waves (wm, wn) and slot that hold group tid of this 64-channel tile
-        float sm;
-        if (p.g_log == 6) sm = (sred[0] + sred[4]) + (sred[8] + sred[12]);
-        else {
-          const int c0 = tid << p.g_log, wn0 = c0 >> 5, q = (c0 & 31) >> p.g_log;
-          sm = sred[wn0 * 4 + q] + sred[(2 + wn0) * 4 + q];
-        }
+        float sm = 0.f;
+        for (int r = tid << rpg_log; r < (tid + 1) << rpg_log; ++r) sm += sred[(r >> 2) * 4 + (r & 3)] + sred[(2 + (r >> 2)) * 4 + (r & 3)];   // waves wm = 0, 1
         if (pass == 0) s_mu[tid] = sm * inv_cnt;
         else {
           const int pidx = (UP ? par * p.tiles_per_img : 0) + tin;

@@ -137,8 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
       const float4 v = R[u];
       if (TF) { w0 = fmaf(v.x, tsc.x, tsh.x); w1 = fmaf(v.y, tsc.y, tsh.y); w2 = fmaf(v.z, tsc.z, tsh.z); w3 = fmaf(v.w, tsc.w, tsh.w); }
       else { w0 = v.x * sc_cur; w1 = v.y * sc_cur; w2 = v.z * sc_cur; w3 = v.w * sc_cur; }
-    } else if constexpr (s == 1) {
-      if (do_load) issue(R[u], msk, u, dl);
+    } else if constexpr (s == 1) {   // (the refill load of R[u] sat here; now one batch per chunk, see run_chunk)
     } else if constexpr (s == 2) {
       if (TF) { const dm_f2 a = dm_f2{w0, w1} * nl2e; ex = dm_f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
     } else if constexpr (s == 3) {
@@ -296,6 +295,13 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
       }
       __builtin_amdgcn_sched_barrier(0);
     });
+    // the refill of R in ONE batch behind the chunk's last staging step: loads return in order, so a wait for a weight fragment
+    // requested after a refill load also waits for that load (HBM latency, not an L2 hit); one batch per chunk is covered by the
+    // fragments' 24-MFMA lead, a refill load behind every piece was not (3x3 layers 128.6 -> 125.0 us)
+    if (do_stage && do_load) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) issue(R[u], msk, u, dl);
+    }
     DM_TL(3);
     if (pre_ts >= 0) next_finish(ts_pre, sc_pre, inv_pre);
   };
@@ -323,6 +329,10 @@ __global__ __launch_bounds__(256, 2) void conv_x6_c3_kernel(const ConvArgs p) {
       constexpr int k = decltype(kc)::value;
       stage_step(RA, mA, std::integral_constant<int, k / NSTEP>{}, std::integral_constant<int, k % NSTEP>{}, tile, d2, two || h1);
     });
+    if (two || h1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) issue(RA[u], mA, u, d2);
+    }
   }
   __syncthreads();
 

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6_down_kernel(const ConvArgs p) 
         if (TF) { w0 = fmaf(v.x, tsc.x, tsh.x); w1 = fmaf(v.y, tsc.y, tsh.y); w2 = fmaf(v.z, tsc.z, tsh.z); w3 = fmaf(v.w, tsc.w, tsh.w); }
         else { w0 = v.x; w1 = v.y; w2 = v.z; w3 = v.w; }
       } break;
-      case 1: if (do_load) issue(R[u], msk, u, gl, ql); break;
+      case 1: break;   // (the refill load of R[u] sat here; now one batch per chunk, see run_chunk)
       case 2: if (TF) { const dm_f2 a = dm_f2{w0, w1} * nl2e; ex = dm_f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; } break;
       case 3: if (TF) {
         const dm_f2 d = ex + one2;
@@ -175,8 +175,10 @@ __global__ __launch_bounds__(256, 2) void conv_x6_down_kernel(const ConvArgs p) 
         rs -= dm_f2{__uint_as_float(q2b << 16), __uint_as_float(q2b & 0xffff0000u)};
         q3b = __builtin_bit_cast(unsigned, __builtin_convertvector(rs, dm_bf2));
       } break;
-      default: if (hyx[u] >= 0) {
-        bf16_t* q = dstb + ldso0 + u * 32 * RSB;
+      default: {
+        // (no branch: behind a condition the compiler sinks the whole piece's arithmetic into the conditional block, one serial blob
+        //  behind one MFMA; a piece outside the plane goes to the 8 unused elements behind pixel 0's 32)
+        bf16_t* q = dstb + (hyx[u] >= 0 ? ldso0 + u * 32 * RSB : KC);
         *reinterpret_cast<uint2*>(q) = make_uint2(q1a, q1b);
         *reinterpret_cast<uint2*>(q + PL) = make_uint2(q2a, q2b);
         if (NS == 3) *reinterpret_cast<uint2*>(q + 2 * PL) = make_uint2(q3a, q3b);
@@ -274,6 +276,13 @@ __global__ __launch_bounds__(256, 2) void conv_x6_down_kernel(const ConvArgs p) 
         }
       }
     }
+    // the refill of R in ONE batch behind the chunk's last staging step: loads return in order, so a wait for a weight fragment
+    // requested after a refill load also waits for that load (HBM latency, not an L2 hit); one batch per chunk is covered by the
+    // fragments' lead, a refill load behind every piece was not
+    if (do_load) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) issue(R[u], msk, u, gl, ql);
+    }
     DM_TL(3);
   };
 
@@ -300,6 +309,8 @@ __global__ __launch_bounds__(256, 2) void conv_x6_down_kernel(const ConvArgs p) 
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s) stage_step(RA, mA, u, s, tile, gcur, 2, true);
+#pragma unroll
+    for (int u = 0; u < U; ++u) issue(RA[u], mA, u, gcur, 2);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll

@@ -116,10 +116,9 @@ def test_x6_conv_fused_groupnorm_silu_temb(kind, H):
 
 
 @pytest.mark.parametrize("C,H", [(128, 16), (128, 32), (256, 16)])
-def test_fp16_3x3_wide_and_four_wave_kernels(C, H):
-    """3x3 in the two-fp16-term form behind a GroupNorm at the widened model's channel counts: C <= 128 runs conv_x6_c3w_kernel
-    (two waves of 64 pixels x 64 channels, four K chunks at C = 128), C = 256 conv_x6_c3_kernel (four waves, its tables are one
-    channel per thread); both against the fp32 reference, GroupNorm partials included (model.py:54-62)."""
+def test_fp16_3x3_at_wider_channel_counts(C, H):
+    """3x3 in the two-fp16-term form behind a GroupNorm at the widened model's channel counts (conv_x6_c3_kernel: four and eight
+    K chunks per tile, groups of 16 and 32 channels) against the fp32 reference, GroupNorm partials included (model.py:54-62)."""
     torch.manual_seed(C + H)
     B = 3
     h_raw = torch.randn(B, C, H, H) * 1.5 - 0.5
