@@ -235,6 +235,12 @@ int launch_conv_x6_down_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t 
   return 0;
 }
 
+// diagnostics only (read once: getenv is neither cheap nor safe beside a concurrent setenv)
+static bool dbg_noswap() {
+  static const bool v = getenv("DM_DEBUG_NOSWAP") != nullptr;
+  return v;
+}
+
 template <bool TF, int HL>
 int launch_conv_x6_c3_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_done[DM_MAX_DEVICES] = {false};
@@ -297,7 +303,7 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   const size_t epi_f = (size_t)g.MT * 68 + 128;  // output staging tile + reduction words
   const int ns = c.x6 >= 2 ? 2 : 3;  // split terms per operand
   const bool f16 = c.x6 == 3;        // two fp16 terms (inputs behind a GroupNorm)
-  if (f16 && ((!c.stats_in && !(kind == 0 && c.amax1 && (!c.c2 || c.amax2))) || g.ni != 1 || getenv("DM_DEBUG_NOSWAP")))
+  if (f16 && ((!c.stats_in && !(kind == 0 && c.amax1 && (!c.c2 || c.amax2))) || g.ni != 1 || dbg_noswap()))
     return fail("conv (fp16 split): inputs behind a GroupNorm (or, 3x3: raw inputs with their producers' maxima), tiles of one image");
   if (c.amax_out && g.ni != 1) return fail("conv: output maxima need tiles of one image");
   size_t lds_f = (c.stats_in ? (size_t)(3 * g.ni) * c.c1 : 0) + (ns * np * 72 + 1) / 2 + 128;  // + reduction words behind the planes
@@ -306,7 +312,7 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   if (lds > 160 * 1024) return fail("conv (split-bf16): tile needs %zu B of LDS (> 160 KiB)", lds);
   // stride-2 conv, one image per tile: the kernel with its staging pipelined into the K loop (dm_kernels_x6p.hip)
   static const bool x6_nopipe = getenv("DM_DEBUG_X6_NOPIPE") != nullptr;  // diagnostics only
-  const bool pipe = kind == 1 && g.ni == 1 && g.tw_log == 3 && g.hth == g.MT / 8 + 1 && g.htw == 9 && !c.c2 && !(c.stats_in && c.no_silu) && !x6_nopipe && !getenv("DM_DEBUG_NOSWAP");
+  const bool pipe = kind == 1 && g.ni == 1 && g.tw_log == 3 && g.hth == g.MT / 8 + 1 && g.htw == 9 && !c.c2 && !(c.stats_in && c.no_silu) && !x6_nopipe && !dbg_noswap();
   if (pipe) {
     const size_t lds_p = ((c.stats_in ? (size_t)3 * c.c1 : 0) + 64) * sizeof(float) + (size_t)2 * ns * np * 40 * 2;
     if (lds_p > 80 * 1024) return fail("conv (split-bf16, stride 2): tile needs %zu B of LDS (> 80 KiB)", lds_p);
@@ -364,7 +370,7 @@ int launch_conv_x6(const ConvCall& c, hipStream_t s) {
   a.stamps = g_stamps;
 #endif
   // one image per tile: swapped MFMA operands, stores straight from the registers (x6_epilogue_sw)
-  static const bool x6_noswap = getenv("DM_DEBUG_NOSWAP") != nullptr;  // diagnostics only
+  const bool x6_noswap = dbg_noswap();
   const bool sw = g.ni == 1 && !x6_noswap;
 #define DM_X6H(MB_, K_) launch_conv_x6_t<MB_, K_, true, 2, true>(a, grid, lds, s)
   if (f16) {
@@ -1153,7 +1159,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     c.x6 = xh ? 3 : xt ? xmode : 0;
     with_tf(w.SB, k2, h, ww, o.g2, o.b2);
     if (am_out) *am_out = no_amax;
-    if (am_buf && am_out && xt && gt.ni == 1 && !getenv("DM_DEBUG_NOSWAP")) {  // (the swapped epilogue writes them)
+    if (am_buf && am_out && xt && gt.ni == 1 && !dbg_noswap()) {  // (the swapped epilogue writes them)
       c.amax_out = am_buf;
       *am_out = AmaxRef{am_buf, gt.pout * (C / 64) * 4};
     }

@@ -376,11 +376,19 @@ __device__ __forceinline__ float wg_scale(float m, float* red4, int wave, float&
   return __uint_as_float((unsigned)(264 - eb) << 23);
 }
 
-// sum over the 64 lanes of a wave, result in every lane
-__device__ __forceinline__ float wave_sum(float v) {
-  v += __shfl_xor(v, 32, 64);
-  v += __shfl_xor(v, 16, 64);
-  return dm_row16_sum(v);
+// sums of four values over the 64 lanes of a wave, every lane receives all four: one halving butterfly (v_permlane32_swap,
+// v_permlane16_swap, DPP row sum: the lanes of row r then hold the total of value r) and four v_readlane, instead of four times
+// two ds_bpermute + a row sum
+__device__ __forceinline__ void wave_sum4(float (&v)[4]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[q]), __float_as_uint(v[q + 2]), false, false);
+    v[q] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[0]), __float_as_uint(v[1]), false, false);
+  const float t = dm_row16_sum(__uint_as_float(r16[0]) + __uint_as_float(r16[1]));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t), 16 * k));
 }
 
 // GroupNorm(8) + SiLU (+ time embedding) of a layer's output IN the accumulator registers.  Statistics: whole-image (mean, M2)
@@ -403,8 +411,9 @@ __device__ __forceinline__ void gn_silu_regs(f32x16& acc, bool valid, float inv_
         const float dlt = acc[4 * k + e] - (pass ? mu[k] : 0.f);
         sm += pass ? dlt * dlt : dlt;
       }
-      val[k] = wave_sum(valid ? sm : 0.f);
+      val[k] = valid ? sm : 0.f;
     }
+    wave_sum4(val);
     if (NW == 2) {
       float* rr = red + pass * 16;
       if ((threadIdx.x & 63) == 0) {
