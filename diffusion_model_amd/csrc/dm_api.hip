@@ -146,6 +146,7 @@ struct ConvCall {
   int B, H, W;
   const float* res; int no_silu;
   int bf16;  // activations and packed weights are bf16 (conv_bf16_kernel)
+  int f16op; // bf16 path, layers behind a GroupNorm: MFMA operands as IEEE half (1: (hi, lo) half weight pairs, 2: one half weight)
   int in_wrap;  // input images n >= in_wrap read image n - in_wrap (3x3 Winograd / bf16 3x3 kernel, one image per tile)
   const float* amax1; const float* amax2; int namax1, namax2;  // x6 == 3 on raw inputs: the producers' maxima (ConvArgs.amax1)
   float* amax_out;                                            // x6 kernels, tiles of one image: maxima of this launch's output
@@ -177,12 +178,12 @@ int launch_conv_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   return 0;
 }
 
-template <int MB, int KIND, bool INIT = false>
+template <int MB, int KIND, bool INIT = false, int F16 = 0>
 int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_done[DM_MAX_DEVICES] = {false};
   const int dev = current_device();
   if (!attr_done[dev]) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MB, KIND, INIT>),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MB, KIND, INIT, F16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
@@ -193,7 +194,7 @@ int launch_conv_bf16_t(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
   const double taps = KIND == 0 ? 9 : KIND == 1 ? 16 : 4;
   const int cin = a.C1 + a.C2;
   ProfScope ps(cls, s, 2.0 * opix * a.Cout * taps * cin, 2.0 * (ipix * cin + opix * a.Cout + taps * (UP ? 4 : 1) * cin * a.Cout));
-  hipLaunchKernelGGL((conv_bf16_kernel<MB, KIND, INIT>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_bf16_kernel<MB, KIND, INIT, F16>), grid, dim3(256), lds, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -482,6 +483,15 @@ int launch_conv(const ConvCall& c, hipStream_t s) {
     // XCD-aware tile order once every XCD has several rounds of work (exact only for 8 | grid.x)
     a.xcd_map = (grid.x % 8 == 0 && grid.y == 1 && grid.z == 1 && groups >= 64) ? 1 : 0;
   }
+  if (c.f16op && (!c.bf16 || !c.stats_in || c.init_x || c.c2 || c.f16op > 2)) return fail("conv: half operands are for the bf16 path's layers behind a GroupNorm");
+  if (c.bf16 && c.f16op) {
+#define DM_BFH(MB_, K_) (c.f16op == 2 ? launch_conv_bf16_t<MB_, K_, false, 2>(a, grid, lds, s) : launch_conv_bf16_t<MB_, K_, false, 1>(a, grid, lds, s))
+    if (c.kind == 0) return g.MT == 128 ? DM_BFH(2, 0) : DM_BFH(1, 0);
+    if (fused_up) return g.MT == 128 ? DM_BFH(2, 4) : DM_BFH(1, 4);
+    if (c.kind == 2) return g.MT == 128 ? DM_BFH(2, 2) : DM_BFH(1, 2);
+    return DM_BFH(1, 1);
+#undef DM_BFH
+  }
   if (c.bf16) {
     if (c.kind == 0 && c.init_x) return g.MT == 128 ? launch_conv_bf16_t<2, 0, true>(a, grid, lds, s) : launch_conv_bf16_t<1, 0, true>(a, grid, lds, s);
     if (c.kind == 0) return g.MT == 128 ? launch_conv_bf16_t<2, 0>(a, grid, lds, s) : launch_conv_bf16_t<1, 0>(a, grid, lds, s);
@@ -551,7 +561,7 @@ int pack_conv(int kind, const float* w, int cin, int cout, float* out, hipStream
   if (bf16) {
     if (kind == 3 || kind == 5) return fail("pack_conv: no bf16 1x1 / Winograd variant");
     hipLaunchKernelGGL(pack_conv_weight_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, kind, w, cin, cout,
-                       reinterpret_cast<bf16_t*>(out), total);
+                       reinterpret_cast<bf16_t*>(out), total, bf16 == 2 ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -582,6 +592,8 @@ struct AttnOff { size_t ng, nb, qkv, qkvb, proj, projb; };
 struct dm_unet {
   int Cin, Cout, C, E;
   int bf16;            // 1: bf16 activations + conv weights (fp32 accumulate / statistics)
+  int bf_h;            // bf16 path: MFMA operands of the layers behind a GroupNorm in down1 / down2.conv2 / up3 as IEEE half
+                       // (0: bf16 as everywhere else, 1: half with (hi, lo) weight pairs, 2: half with one weight; DM_BF16_F16)
   int x6;              // fp32 path: which convolutions run on the bf16 pipe with three-way split operands (conv_x6_kernel):
                        // bit 0 stride-2 4x4, bit 1 transposed 4x4, bit 2 3x3 below 8x8, bit 3 every 3x3
   int attn;            // build-defined attention blocks at 1/4 resolution (after down2 and up1)
@@ -599,6 +611,14 @@ struct dm_unet {
 };
 
 namespace {
+
+// bf16 path: does layer `which` (1: the stride-2 / transposed transform, 2: conv2 - both read SiLU(GroupNorm(.))) of block k
+// take its MFMA operands as IEEE half (conv_bf16_kernel's F16 forms)?  The blocks at the highest resolution (down1, up3) and
+// down2.conv2; a property of the model only (the fused low-resolution kernel keeps bf16 operands for every layer it covers, from
+// down2.transform to up2.transform, and reads those layers' (hi, lo) bf16 packs).
+inline bool bf_half_layer(const dm_unet* m, int k, int which) {
+  return m->bf16 && m->bf_h && which != 0 && (k == 0 || k == 5 || (k == 1 && which == 2));
+}
 
 struct Workspace {
   float *A0, *T1, *T2, *D1, *D2, *D3, *BT0, *BT, *U1, *U2, *SA, *SB, *heads, *temb, *eps, *xx;
@@ -1138,6 +1158,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     const int k2 = c2h ? 0 : kd;
     base(k2, w.T1, C, nullptr, 0, c2h ? o.c2h : xs ? o.c2x : k2 == 5 ? o.c2w : o.c2, o.c2b, w.T2, w.SB, h, ww);
     c.x6 = c2h ? 3 : xs ? xmode : 0;  // (c2h implies h * w >= 64, where xs is off unless DM_X6 bit 3 is set)
+    c.f16op = bf_half_layer(m, k, 2) ? m->bf_h : 0;
     c.in_wrap = shared1 ? dup_half : 0;
     with_tf(w.SA, k1, h, ww, o.g1, o.b1);
     c.temb = heads + (size_t)k * C; c.temb_stride = heads_img_stride; c.temb_step_stride = heads_step_stride;
@@ -1157,6 +1178,7 @@ int unet_body(const dm_unet* m, const float* P, const float* x, float* eps, cons
     const bool xh = xt && xmode == 1 && (x6 & 32) && gt.ni == 1;
     base(up ? 2 : kdn, w.T2, C, nullptr, 0, xh ? o.trh : xt ? o.trx : o.tr, o.trb, out, out_stats, h, ww);
     c.x6 = xh ? 3 : xt ? xmode : 0;
+    c.f16op = bf_half_layer(m, k, 1) ? m->bf_h : 0;
     with_tf(w.SB, k2, h, ww, o.g2, o.b2);
     if (am_out) *am_out = no_amax;
     if (am_buf && am_out && xt && gt.ni == 1 && !dbg_noswap()) {  // (the swapped epilogue writes them)
@@ -1358,6 +1380,7 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
   m->x6 = getenv("DM_X6") ? atoi(getenv("DM_X6")) & 511 : DM_X6_DEFAULT;
   m->init5 = getenv("DM_INIT5") ? (atoi(getenv("DM_INIT5")) != 0) : 1;
   m->lowres = getenv("DM_LOWRES") ? (atoi(getenv("DM_LOWRES")) != 0) : 1;
+  m->bf_h = getenv("DM_BF16_F16") ? (atoi(getenv("DM_BF16_F16")) % 3) : 2;
   const int C = m->C, E = m->E;
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
@@ -1454,10 +1477,10 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
                pack_conv(15, p[i], up ? 2 * C : C, C, packed + b.c1h, s))) return 1;
     if (pack_conv(0, p[i++], up ? 2 * C : C, C, packed + b.c1, s, m->bf16) || copy(b.c1b, p[i++], C)) return 1;
     if (xf && (pack_conv(up ? 9 : 8, p[i], C, C, packed + b.trx, s) || pack_conv(up ? 14 : 13, p[i], C, C, packed + b.trh, s))) return 1;
-    if (pack_conv(up ? 2 : 1, p[i++], C, C, packed + b.tr, s, m->bf16) || copy(b.trb, p[i++], C)) return 1;
+    if (pack_conv(up ? 2 : 1, p[i++], C, C, packed + b.tr, s, bf_half_layer(m, k, 1) ? 2 : m->bf16) || copy(b.trb, p[i++], C)) return 1;
     if (xf && (pack_conv(5, p[i], C, C, packed + b.c2w, s) || pack_conv(7, p[i], C, C, packed + b.c2x, s) ||
                pack_conv(15, p[i], C, C, packed + b.c2h, s))) return 1;
-    if (pack_conv(0, p[i++], C, C, packed + b.c2, s, m->bf16) || copy(b.c2b, p[i++], C)) return 1;
+    if (pack_conv(0, p[i++], C, C, packed + b.c2, s, bf_half_layer(m, k, 2) ? 2 : m->bf16) || copy(b.c2b, p[i++], C)) return 1;
     if (copy(b.g1, p[i++], C) || copy(b.b1, p[i++], C) || copy(b.g2, p[i++], C) || copy(b.b2, p[i++], C)) return 1;
     return 0;
   };

@@ -28,7 +28,19 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 #ifndef DM_BF16_SPLITW
 #define DM_BF16_SPLITW 1
 #endif
-template <int MB, int KIND, bool INIT = false>  // INIT: down1.conv1 with init_conv folded into its staging
+// F16 (layers behind a GroupNorm only: conv2, the stride-2 / transposed transforms of the blocks at the two highest resolutions):
+// the MFMA operands are IEEE half instead of bf16 - SiLU(GroupNorm(.)) + temb is of order 1, where half's 11 bits cost what
+// bf16's 8 bits cost and round 8x finer; the activation operand's bf16 rounding in down1 / up3 was the largest share of the
+// path's eps error.  F16 = 1: weights as a (hi, lo) half pair, two MFMAs per product; F16 = 2: ONE half
+// weight (rounded to nearest, 2^-12 relative: the same size as the activation's rounding), one v_mfma_f32_32x32x16_f16 per product.
+typedef _Float16 bf_h2v __attribute__((ext_vector_type(2)));
+typedef _Float16 bf_h8v __attribute__((ext_vector_type(8)));
+typedef float bf_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf_pack_h2(float a, float b) {  // two floats -> packed half, to nearest even; clamped like f2h
+  const bf_f2v v = {__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f)};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf_h2v));
+}
+template <int MB, int KIND, bool INIT = false, int F16 = 0>  // INIT: down1.conv1 with init_conv folded into its staging
 __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvArgs p) {
   constexpr int KC = 64;
   constexpr int MT = 64 * MB;
@@ -167,8 +179,13 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
             } else {
               e0 += te.x; e1 += te.y; e2 += te.z; e3 += te.w;
             }
-            wi[q] = (unsigned)f2bf(e0) | ((unsigned)f2bf(e1) << 16);
-            wi[q + 1] = (unsigned)f2bf(e2) | ((unsigned)f2bf(e3) << 16);
+            if constexpr (F16 != 0) {
+              wi[q] = bf_pack_h2(e0, e1);
+              wi[q + 1] = bf_pack_h2(e2, e3);
+            } else {
+              wi[q] = (unsigned)f2bf(e0) | ((unsigned)f2bf(e1) << 16);
+              wi[q + 1] = (unsigned)f2bf(e2) | ((unsigned)f2bf(e3) << 16);
+            }
           }
           w = make_uint4(wi[0], wi[1], wi[2], wi[3]);
         }
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         bq[j] = *reinterpret_cast<const uint4*>(wbase + j * jstride);
-        bl[j] = *reinterpret_cast<const uint4*>(wbase + lo_off + j * jstride);
+        if constexpr (F16 != 2) bl[j] = *reinterpret_cast<const uint4*>(wbase + lo_off + j * jstride);
       }
       __syncthreads();
       __builtin_amdgcn_s_setprio(0);
@@ -249,16 +266,26 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
 #pragma unroll
           for (int mb = 0; mb < MB; ++mb) anxt[mb] = *reinterpret_cast<const uint4*>(tile + abase[mb] + noff);
           __builtin_amdgcn_sched_barrier(0);
-          const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bq[j]);
-          const bf16x8_t bw = __builtin_bit_cast(bf16x8_t, bl[j]);
+          if constexpr (F16 != 0) {
+            const bf_h8v bh = __builtin_bit_cast(bf_h8v, bq[j]);
 #pragma unroll
-          for (int mb = 0; mb < MB; ++mb) {
-            const bf16x8_t av = __builtin_bit_cast(bf16x8_t, acur[mb]);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc[mb], 0, 0, 0);
-            if (DM_BF16_SPLITW) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc[mb], 0, 0, 0);
+            for (int mb = 0; mb < MB; ++mb) {
+              const bf_h8v av = __builtin_bit_cast(bf_h8v, acur[mb]);
+              if constexpr (F16 == 1) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(bf_h8v, bl[j]), acc[mb], 0, 0, 0);
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bh, acc[mb], 0, 0, 0);
+            }
+          } else {
+            const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, bq[j]);
+            const bf16x8_t bw = __builtin_bit_cast(bf16x8_t, bl[j]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+              const bf16x8_t av = __builtin_bit_cast(bf16x8_t, acur[mb]);
+              acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bh, acc[mb], 0, 0, 0);
+              if (DM_BF16_SPLITW) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bw, acc[mb], 0, 0, 0);
+            }
           }
           bq[j] = *reinterpret_cast<const uint4*>(wnext + j * jstride);
-          bl[j] = *reinterpret_cast<const uint4*>(wnext + lo_off + j * jstride);
+          if constexpr (F16 != 2) bl[j] = *reinterpret_cast<const uint4*>(wnext + lo_off + j * jstride);
           __builtin_amdgcn_sched_barrier(0);
         }
         tx = ntx; ty = nty;
@@ -287,8 +314,9 @@ __global__ __launch_bounds__(256, DM_BF16_WG) void conv_bf16_kernel(const ConvAr
 // bf16 B-fragment packing, each weight as a (hi, lo) bf16 pair with hi + lo ~ w to 16 mantissa bits:
 //   out[par][tap][cin/16][cout/32][lane][8] = hi = bf16( w(cout = nb*32 + (lane&31), cin = 16*c16 + 8*(lane>>5) + e, ky, kx) )
 //   out[total + the same index]             = lo = bf16( w - hi )
+// half != 0 (conv_bf16_kernel's F16 layers): the pair as IEEE half, hi to nearest - alone it is the single-weight form.
 __global__ void pack_conv_weight_bf16_kernel(int kind, const float* __restrict__ w, int cin, int cout,
-                                             bf16_t* __restrict__ out, size_t total) {
+                                             bf16_t* __restrict__ out, size_t total, int half) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int nty = kind == 0 ? 3 : kind == 1 ? 4 : 2;
@@ -309,6 +337,12 @@ __global__ void pack_conv_weight_bf16_kernel(int kind, const float* __restrict__
   const size_t src = (kind == 2) ? (((size_t)ci * cout + co) * ks + ky) * ks + kx
                                  : (((size_t)co * cin + ci) * ks + ky) * ks + kx;
   const float wv = w[src];
+  if (half) {
+    const bf16_t hi = f2h(wv);
+    out[idx] = hi;
+    out[total + idx] = f2h(wv - h2f(hi));
+    return;
+  }
   const bf16_t hi = f2bf(wv);
   out[idx] = hi;
   out[total + idx] = f2bf(wv - bf2f(hi));
