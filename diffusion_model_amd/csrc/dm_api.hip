@@ -581,7 +581,7 @@ struct BlockOff { size_t tmw, tmb, c1, c1b, c2, c2b, tr, trb, g1, b1, g2, b2, c1
 // workspace, the weights and everything the carve layout / launch sequence depends on.
 struct GraphEntry {
   const void *packed, *ws;
-  int B, H, W, S, n, cfg, noise, bf16;
+  int B, H, W, S, n, cfg, noise, bf16, nsplit;
   float guidance;
   hipGraph_t graph;
   hipGraphExec_t exec;
@@ -608,6 +608,9 @@ struct dm_unet {
                        // otherwise every geometry runs on the any-geometry kernels (dm_kernels_generic.hip)
   size_t total;
   std::vector<GraphEntry> graphs;
+  // dm_sample's parallel branches (sample_split): side streams and fork / join events, created on first use, per device
+  hipStream_t split_streams[DM_MAX_DEVICES][3] = {};
+  hipEvent_t split_events[DM_MAX_DEVICES][4] = {};
 };
 
 namespace {
@@ -1430,6 +1433,10 @@ int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int mode
 
 void dm_unet_destroy(dm_unet* m) {
   if (!m) return;
+  for (int d = 0; d < DM_MAX_DEVICES; ++d) {
+    for (auto& st : m->split_streams[d]) if (st) (void)hipStreamDestroy(st);
+    for (auto& ev : m->split_events[d]) if (ev) (void)hipEventDestroy(ev);
+  }
   for (auto& g : m->graphs) {
     (void)hipGraphExecDestroy(g.exec);
     (void)hipGraphDestroy(g.graph);
@@ -1587,11 +1594,38 @@ int dm_sampler_coefs(const float* acp, const float* acp_prev, const float* pv, i
   return 0;
 }
 
+// Into how many sub-batches does dm_sample cut the B images of a captured loop?  The sub-batches are independent sampling chains
+// (per-image results do not depend on the batch an image rides in: kernel choice by geometry only), captured as PARALLEL
+// branches of the graph on side streams: the latency-bound launches of one chain (a few workgroups per layer below 16x16, the
+// fused low-resolution kernel with one workgroup per image) run beside the other chains' kernels, and the tail of every
+// persistent launch is filled by the neighbour's head.  A scheduling decision only - results are bit-identical for any split
+// (test_split_batches_are_bit_identical).  Not with guidance (the doubled batch shares its first layers) and not in eager mode.
+// Measured (tools/diag/r3_split_ab*.sh, DDIM-50, 32x32 C=64, same box, 1 -> 4 branches): B=128 -1.5 %, B=256 +11 %, B=512 +3.3 %,
+// B=1024 +2.6 % (two branches +3.2 %), B=2048 +1.3 %, B=8192 +0.8 %; ancestral-1000 B=256 +9 %, B=64 (two branches of 32) -4 %;
+// bf16 B=1024 +4.2 %; widened 64x64 C=256 B=256 +-0, with attention +2 %.  Hence: four branches once a branch still fills the
+// chip's workgroup slots with its largest layer (>= 64 images of 32x32), none below.  DM_SPLIT = k forces k (read per call).
+static int sample_split(const dm_unet* m, int B, int H, int W, int guided) {
+  const char* env = getenv("DM_SPLIT");
+  const int forced = env ? atoi(env) : 0;
+  if (guided || B < 2) return 1;
+  int k = forced > 0 ? forced : ((size_t)B * H * W >= ((size_t)256 << 10) ? 4 : 1);
+  if (k > 4) k = 4;
+  while (k > 1 && B % k) --k;
+  (void)m;
+  return k < 1 ? 1 : k;
+}
+
 size_t dm_sample_workspace_bytes(const dm_unet* m, int B, int H, int W, int n, int guided, int with_noise) {
   if (!m || B <= 0 || H <= 0 || W <= 0 || n <= 0) return 0;
   const int S0 = n < 50 ? n : 50;
   const size_t count = (size_t)B * m->Cin * H * W;
-  return carve(m, nullptr, guided ? 2 * B : B, H, W, n, with_noise ? (size_t)S0 * count : 0).bytes;
+  size_t need = carve(m, nullptr, guided ? 2 * B : B, H, W, n, with_noise ? (size_t)S0 * count : 0).bytes;
+  const int ns = sample_split(m, B, H, W, guided);
+  if (ns > 1) {  // one carve per sub-batch, back to back
+    const size_t sub = (size_t)ns * carve(m, nullptr, B / ns, H, W, n, with_noise ? (size_t)S0 * (count / ns) : 0).bytes;
+    if (sub > need) need = sub;
+  }
+  return need;
 }
 
 int dm_sample(dm_unet* m, const float* packed, float* x, int B, int H, int W, const int64_t* ts,
@@ -1615,12 +1649,35 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
   const int Bd = cfg ? 2 * B : B;  // denoiser batch
   const int S0 = n < 50 ? n : 50;  // steps per graph (and per noise staging chunk)
   const size_t count = (size_t)B * m->Cin * H * W;
-  Workspace w = carve(m, ws, Bd, H, W, n, noise ? (size_t)S0 * count : 0);
-  if (ws_bytes < w.bytes) return fail("workspace too small: %zu < %zu bytes (dm_sample_workspace_bytes)", ws_bytes, w.bytes);
   hipStream_t s = (hipStream_t)stream;
+  // sub-batches as parallel branches of the captured loop (sample_split); NS = 1: the whole batch on the caller's stream
+  const int NS = (use_graph && s) ? sample_split(m, B, H, W, cfg) : 1;
+  const int Bk = B / NS;                        // images per sub-batch (NS divides B)
+  const size_t countk = count / NS;
+  Workspace wsub[4];
+  wsub[0] = carve(m, ws, NS > 1 ? Bk : Bd, H, W, n, noise ? (size_t)S0 * countk : 0);
+  for (int k = 1; k < NS; ++k) {
+    wsub[k] = carve(m, reinterpret_cast<char*>(ws) + (size_t)k * wsub[0].bytes, Bk, H, W, n, noise ? (size_t)S0 * countk : 0);
+    // one set of per-step tables and one step counter for all branches
+    wsub[k].heads = wsub[0].heads; wsub[k].temb = wsub[0].temb; wsub[k].coefs = wsub[0].coefs; wsub[k].ts = wsub[0].ts; wsub[k].step = wsub[0].step;
+  }
+  const Workspace& w = wsub[0];
+  if (ws_bytes < (size_t)NS * w.bytes) return fail("workspace too small: %zu < %zu bytes (dm_sample_workspace_bytes)", ws_bytes, (size_t)NS * w.bytes);
+  hipStream_t sk[4] = {s, nullptr, nullptr, nullptr};
+  hipEvent_t* ev = nullptr;
+  if (NS > 1) {
+    const int dev = current_device();
+    for (int k = 1; k < NS; ++k) {
+      if (!m->split_streams[dev][k - 1]) HIP_TRY(hipStreamCreateWithFlags(&m->split_streams[dev][k - 1], hipStreamNonBlocking));
+      sk[k] = m->split_streams[dev][k - 1];
+    }
+    for (int k = 0; k < 4; ++k)
+      if (!m->split_events[dev][k]) HIP_TRY(hipEventCreateWithFlags(&m->split_events[dev][k], hipEventDisableTiming));
+    ev = m->split_events[dev];
+  }
   // Every operand the step kernels read is staged into the workspace, so a captured graph holds
   // workspace addresses only and is reusable whatever buffers the next call brings.
-  HIP_TRY(hipMemcpyAsync(w.xcur, x, count * sizeof(float), hipMemcpyDefault, s));
+  for (int k = 0; k < NS; ++k) HIP_TRY(hipMemcpyAsync(wsub[k].xcur, x + (size_t)k * countk, countk * sizeof(float), hipMemcpyDefault, s));
   HIP_TRY(hipMemcpyAsync(w.ts, ts, (size_t)n * sizeof(int64_t), hipMemcpyDefault, s));
   HIP_TRY(hipMemcpyAsync(w.coefs, coefs, (size_t)n * 8 * sizeof(float), hipMemcpyDefault, s));
   if (cfg) HIP_TRY(hipMemcpyAsync(w.cond, cond, (size_t)Bd * m->E * sizeof(float), hipMemcpyDefault, s));
@@ -1630,34 +1687,36 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
   // (guidance: the time MLP of all n steps once - it depends on t only -; per step only the heads of time + class embedding)
   if (cfg && launch_time_embed(m, packed, w.ts, n, nullptr, w.temb, w.heads, s)) return 1;
   const int hstep = 6 * m->C;
-  float* xc = w.xcur;
 
-  // step index = *step_ptr + step_off (tables); `local` = index into the staged noise chunk
-  auto one_step = [&](const int* step_ptr, int step_off, int local) -> int {
+  // one step of sub-batch k on its stream; step index = *step_ptr + step_off (tables); `local` = index into the staged noise chunk
+  auto one_step = [&](int k, const int* step_ptr, int step_off, int local) -> int {
+    const Workspace& wk = wsub[k];
+    hipStream_t st = sk[k];
+    float* xc = wk.xcur;
     if (!cfg) {
       if (fuses_step(m, H, W)) {  // the update rides in final_conv's store: x is read and rewritten in place, element by element
         FinalStep fsx;
         memset(&fsx, 0, sizeof fsx);
-        fsx.x = xc; fsx.noise = noise ? w.noise : nullptr; fsx.coefs = w.coefs; fsx.step_ptr = step_ptr; fsx.xout = xc;
-        fsx.count = count; fsx.step_off = step_off; fsx.noise_idx = local;
-        return unet_body(m, packed, xc, w.eps, w.heads, 0, hstep, step_ptr, step_off, w, Bd, H, W, s, 0, &fsx);
+        fsx.x = xc; fsx.noise = noise ? wk.noise : nullptr; fsx.coefs = wk.coefs; fsx.step_ptr = step_ptr; fsx.xout = xc;
+        fsx.count = countk; fsx.step_off = step_off; fsx.noise_idx = local;
+        return unet_body(m, packed, xc, wk.eps, wk.heads, 0, hstep, step_ptr, step_off, wk, Bk, H, W, st, 0, &fsx);
       }
-      if (unet_body(m, packed, xc, w.eps, w.heads, 0, hstep, step_ptr, step_off, w, Bd, H, W, s)) return 1;
-      return launch_step(xc, w.eps, noise ? w.noise : nullptr, local, w.coefs, step_ptr, step_off, nullptr, xc, count, 0, 0.f, s);
+      if (unet_body(m, packed, xc, wk.eps, wk.heads, 0, hstep, step_ptr, step_off, wk, Bk, H, W, st)) return 1;
+      return launch_step(xc, wk.eps, noise ? wk.noise : nullptr, local, wk.coefs, step_ptr, step_off, nullptr, xc, countk, 0, 0.f, st);
     }
-    // doubled batch [x;x] with embeddings [cond ; null] (build-defined CFG)
+    // doubled batch [x;x] with embeddings [cond ; null] (build-defined CFG; never split: NS = 1, countk = count)
     // (when block 0 is evaluated once for both halves, only x itself is read: no duplicate needed)
     const bool shared = shares_first_layers(m, Bd, H, W, B);
     if (!shared) {
       size_t blocks = (count + 255) / 256;
       if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(dup_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xc, w.xx, count);
+      hipLaunchKernelGGL(dup_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xc, wk.xx, count);
       HIP_TRY(hipGetLastError());
     }
     static const bool no_table = getenv("DM_DEBUG_NO_TEMB_TABLE") != nullptr;  // diagnostics only: the time MLP per entry and step, as before
-    if (launch_time_embed(m, packed, w.ts, Bd, w.cond, nullptr, w.heads, s, step_ptr, step_off, 0, no_table ? nullptr : w.temb)) return 1;
-    if (unet_body(m, packed, shared ? xc : w.xx, w.eps, w.heads, hstep, 0, nullptr, 0, w, Bd, H, W, s, B)) return 1;
-    return launch_step(xc, w.eps, noise ? w.noise : nullptr, local, w.coefs, step_ptr, step_off, nullptr, xc, count, 1, guidance, s);
+    if (launch_time_embed(m, packed, wk.ts, Bd, wk.cond, nullptr, wk.heads, st, step_ptr, step_off, 0, no_table ? nullptr : wk.temb)) return 1;
+    if (unet_body(m, packed, shared ? xc : wk.xx, wk.eps, wk.heads, hstep, 0, nullptr, 0, wk, Bd, H, W, st, B)) return 1;
+    return launch_step(xc, wk.eps, noise ? wk.noise : nullptr, local, wk.coefs, step_ptr, step_off, nullptr, xc, count, 1, guidance, st);
   };
   // noise of steps [first, first + cnt) -> staging area (noise: [n][count], device or host memory)
   // The chunk callback runs on the calling thread BEFORE the chunk is enqueued (everything before `first` already is): it
@@ -1673,16 +1732,23 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
       }
     }
     if (!noise) return 0;
-    HIP_TRY(hipMemcpyAsync(w.noise, src, (size_t)cnt * count * sizeof(float), hipMemcpyDefault, s));
+    if (NS == 1) {
+      HIP_TRY(hipMemcpyAsync(w.noise, src, (size_t)cnt * count * sizeof(float), hipMemcpyDefault, s));
+      return 0;
+    }
+    // sub-batch k takes columns [k countk, (k + 1) countk) of every step's row: [cnt][count] -> [cnt][countk]
+    for (int k = 0; k < NS; ++k)
+      HIP_TRY(hipMemcpy2DAsync(wsub[k].noise, countk * sizeof(float), src + (size_t)k * countk, count * sizeof(float), countk * sizeof(float),
+                               (size_t)cnt, hipMemcpyDefault, s));
     return 0;
   };
 
   if (!use_graph) {
     for (int i = 0; i < n; ++i) {
       if (i % S0 == 0 && stage_noise(i, n - i < S0 ? n - i : S0)) return 1;
-      if (one_step(nullptr, i, i % S0)) return 1;
+      if (one_step(0, nullptr, i, i % S0)) return 1;
     }
-    HIP_TRY(hipMemcpyAsync(x, xc, count * sizeof(float), hipMemcpyDefault, s));
+    HIP_TRY(hipMemcpyAsync(x, w.xcur, count * sizeof(float), hipMemcpyDefault, s));
     return 0;
   }
   if (!s) return fail("dm_sample: graph capture needs a non-default stream");
@@ -1691,16 +1757,27 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
   auto get_graph = [&](int S, hipGraphExec_t* exec) -> int {
     for (auto& g : m->graphs)
       if (g.packed == packed && g.ws == ws && g.B == B && g.H == H && g.W == W && g.S == S && g.n == n &&
-          g.cfg == cfg && g.noise == (noise ? 1 : 0) && g.guidance == guidance && g.bf16 == m->bf16) {
+          g.cfg == cfg && g.noise == (noise ? 1 : 0) && g.guidance == guidance && g.bf16 == m->bf16 && g.nsplit == NS) {
         *exec = g.exec;
         return 0;
       }
     GraphEntry e;
     e.packed = packed; e.ws = ws; e.B = B; e.H = H; e.W = W; e.S = S; e.n = n; e.cfg = cfg; e.noise = noise ? 1 : 0;
-    e.guidance = guidance; e.bf16 = m->bf16;
+    e.guidance = guidance; e.bf16 = m->bf16; e.nsplit = NS;
     HIP_TRY(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int rc = 0;
-    for (int i = 0; i < S && !rc; ++i) rc = one_step(w.step, i, i);
+    // fork: the side streams join the capture behind the caller's stream; every branch then runs its S steps on its own
+    if (NS > 1) {
+      if (hipEventRecord(ev[0], s) != hipSuccess) rc = fail("dm_sample: fork event");
+      for (int k = 1; k < NS && !rc; ++k)
+        if (hipStreamWaitEvent(sk[k], ev[0], 0) != hipSuccess) rc = fail("dm_sample: fork wait");
+    }
+    for (int k = 0; k < NS && !rc; ++k)
+      for (int i = 0; i < S && !rc; ++i) rc = one_step(k, w.step, i, i);
+    // join: the step counter advances when every branch is through
+    for (int k = 1; k < NS && !rc; ++k) {
+      if (hipEventRecord(ev[k], sk[k]) != hipSuccess || hipStreamWaitEvent(s, ev[k], 0) != hipSuccess) rc = fail("dm_sample: join");
+    }
     if (!rc) {
       hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, s, w.step, S);
       if (hipGetLastError() != hipSuccess) rc = fail("advance_step launch failed");
@@ -1731,7 +1808,7 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
     if (stage_noise(n - n % S0, n % S0)) return 1;
     HIP_TRY(hipGraphLaunch(ex, s));
   }
-  HIP_TRY(hipMemcpyAsync(x, xc, count * sizeof(float), hipMemcpyDefault, s));
+  for (int k = 0; k < NS; ++k) HIP_TRY(hipMemcpyAsync(x + (size_t)k * countk, wsub[k].xcur, countk * sizeof(float), hipMemcpyDefault, s));
   return 0;
 }
 

@@ -113,3 +113,33 @@ def test_update_folded_into_final_conv_equals_separate_step(model, kind, eta, B)
                 kw = {"noise": nz[i].to(DEV)} if eta > 0 else {}
                 x = smp.step(eps, t, x, **kw)
         assert torch.equal(got, x), (kind, use_graph)
+
+
+@pytest.mark.parametrize("kind,n,eta,B,split", [("ddim", 12, 0.0, 8, 4), ("ddim", 60, 0.5, 6, 4), ("ancestral", 130, 1.0, 4, 2),
+                                                ("ddim", 5, 0.0, 320, 0)])
+def test_split_batches_are_bit_identical(model, monkeypatch, kind, n, eta, B, split):
+    """dm_sample cuts large batches into sub-batches that run as parallel branches of the captured loop (side streams forked
+    and joined inside the graph, one workspace carve and one noise staging area per branch; sample_split in dm_api.hip).  A
+    scheduling decision only: the samples equal the single-branch run bit for bit - DDIM and ancestral, with noise (eta > 0:
+    each branch reads its columns of the staged chunk), across graph chunks (n > 50), for a branch count that had to be
+    reduced to divide B (6 images, 4 asked -> 3), and with the library's own choice (split = 0: 320 images of 32x32 -> 4)."""
+    sched = d.DDPMScheduler()
+    smp = (d.DDIMSampler(sched, num_inference_steps=n, eta=eta) if kind == "ddim"
+           else d.AncestralSampler(sched, num_inference_steps=1000, eta=eta))
+    if kind == "ancestral":
+        sched.timesteps = sched.timesteps[:n]
+    n = sched.timesteps.numel()  # (DDIM: range(0, T, T // n) may hold a few more than n steps, schedulers.py:154-158)
+    g = torch.Generator().manual_seed(B + n)
+    x_T = torch.randn((B, 1, 32, 32), generator=g)
+    nz = torch.randn((n, B, 1, 32, 32), generator=g) if eta > 0 else None
+    monkeypatch.setenv("DM_SPLIT", "1")
+    want = smp.sample_from(model, x_T, nz)
+    if split:
+        monkeypatch.setenv("DM_SPLIT", str(split))
+    else:
+        monkeypatch.delenv("DM_SPLIT")
+    got = smp.sample_from(model, x_T, nz)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want)
+    # ... and a second call reuses the cached multi-branch graph
+    assert torch.equal(smp.sample_from(model, x_T, nz), want)
