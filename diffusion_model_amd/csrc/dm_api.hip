@@ -1599,7 +1599,7 @@ int dm_sampler_coefs(const float* acp, const float* acp_prev, const float* pv, i
 // branches of the graph on side streams: the latency-bound launches of one chain (a few workgroups per layer below 16x16, the
 // fused low-resolution kernel with one workgroup per image) run beside the other chains' kernels, and the tail of every
 // persistent launch is filled by the neighbour's head.  A scheduling decision only - results are bit-identical for any split
-// (test_split_batches_are_bit_identical).  Not with guidance (the doubled batch shares its first layers) and not in eager mode.
+// (test_split_batches_are_bit_identical).  With guidance every sub-batch is its own doubled batch [x_k ; x_k].  Not in eager mode.
 // Measured (tools/diag/r3_split_ab*.sh, DDIM-50, 32x32 C=64, same box, 1 -> 4 branches): B=128 -1.5 %, B=256 +11 %, B=512 +3.3 %,
 // B=1024 +2.6 % (two branches +3.2 %), B=2048 +1.3 %, B=8192 +0.8 %; ancestral-1000 B=256 +9 %, B=64 (two branches of 32) -4 %;
 // bf16 B=1024 +4.2 %; widened 64x64 C=256 B=256 +-0, with attention +2 %.  Hence: four branches once a branch still fills the
@@ -1607,7 +1607,7 @@ int dm_sampler_coefs(const float* acp, const float* acp_prev, const float* pv, i
 static int sample_split(const dm_unet* m, int B, int H, int W, int guided) {
   const char* env = getenv("DM_SPLIT");
   const int forced = env ? atoi(env) : 0;
-  if (guided || B < 2) return 1;
+  if (B < 2) return 1;
   int k = forced > 0 ? forced : ((size_t)B * H * W >= ((size_t)256 << 10) ? 4 : 1);
   if (k > 4) k = 4;
   while (k > 1 && B % k) --k;
@@ -1622,7 +1622,7 @@ size_t dm_sample_workspace_bytes(const dm_unet* m, int B, int H, int W, int n, i
   size_t need = carve(m, nullptr, guided ? 2 * B : B, H, W, n, with_noise ? (size_t)S0 * count : 0).bytes;
   const int ns = sample_split(m, B, H, W, guided);
   if (ns > 1) {  // one carve per sub-batch, back to back
-    const size_t sub = (size_t)ns * carve(m, nullptr, B / ns, H, W, n, with_noise ? (size_t)S0 * (count / ns) : 0).bytes;
+    const size_t sub = (size_t)ns * carve(m, nullptr, (guided ? 2 : 1) * (B / ns), H, W, n, with_noise ? (size_t)S0 * (count / ns) : 0).bytes;
     if (sub > need) need = sub;
   }
   return need;
@@ -1653,13 +1653,15 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
   // sub-batches as parallel branches of the captured loop (sample_split); NS = 1: the whole batch on the caller's stream
   const int NS = (use_graph && s) ? sample_split(m, B, H, W, cfg) : 1;
   const int Bk = B / NS;                        // images per sub-batch (NS divides B)
+  const int Bdk = Bd / NS;                      // its denoiser batch
   const size_t countk = count / NS;
   Workspace wsub[4];
-  wsub[0] = carve(m, ws, NS > 1 ? Bk : Bd, H, W, n, noise ? (size_t)S0 * countk : 0);
+  wsub[0] = carve(m, ws, Bdk, H, W, n, noise ? (size_t)S0 * countk : 0);
   for (int k = 1; k < NS; ++k) {
-    wsub[k] = carve(m, reinterpret_cast<char*>(ws) + (size_t)k * wsub[0].bytes, Bk, H, W, n, noise ? (size_t)S0 * countk : 0);
-    // one set of per-step tables and one step counter for all branches
-    wsub[k].heads = wsub[0].heads; wsub[k].temb = wsub[0].temb; wsub[k].coefs = wsub[0].coefs; wsub[k].ts = wsub[0].ts; wsub[k].step = wsub[0].step;
+    wsub[k] = carve(m, reinterpret_cast<char*>(ws) + (size_t)k * wsub[0].bytes, Bdk, H, W, n, noise ? (size_t)S0 * countk : 0);
+    // one set of per-step tables and one step counter for all branches (with guidance the heads are per image: each branch its own)
+    if (!cfg) wsub[k].heads = wsub[0].heads;
+    wsub[k].temb = wsub[0].temb; wsub[k].coefs = wsub[0].coefs; wsub[k].ts = wsub[0].ts; wsub[k].step = wsub[0].step;
   }
   const Workspace& w = wsub[0];
   if (ws_bytes < (size_t)NS * w.bytes) return fail("workspace too small: %zu < %zu bytes (dm_sample_workspace_bytes)", ws_bytes, (size_t)NS * w.bytes);
@@ -1680,7 +1682,11 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
   for (int k = 0; k < NS; ++k) HIP_TRY(hipMemcpyAsync(wsub[k].xcur, x + (size_t)k * countk, countk * sizeof(float), hipMemcpyDefault, s));
   HIP_TRY(hipMemcpyAsync(w.ts, ts, (size_t)n * sizeof(int64_t), hipMemcpyDefault, s));
   HIP_TRY(hipMemcpyAsync(w.coefs, coefs, (size_t)n * 8 * sizeof(float), hipMemcpyDefault, s));
-  if (cfg) HIP_TRY(hipMemcpyAsync(w.cond, cond, (size_t)Bd * m->E * sizeof(float), hipMemcpyDefault, s));
+  if (cfg)  // cond = [B conditional rows ; B null rows]: branch k takes its Bk rows of each half
+    for (int k = 0; k < NS; ++k)
+      for (int hf = 0; hf < 2; ++hf)
+        HIP_TRY(hipMemcpyAsync(wsub[k].cond + (size_t)hf * Bk * m->E, cond + ((size_t)hf * B + (size_t)k * Bk) * m->E, (size_t)Bk * m->E * sizeof(float),
+                               hipMemcpyDefault, s));
   // Time embeddings of all n steps up front: they depend on t only.  With
   // guidance every image has its own embedding (time + class): computed per step for 2B rows.
   if (!cfg && launch_time_embed(m, packed, w.ts, n, nullptr, nullptr, w.heads, s)) return 1;
@@ -1699,24 +1705,24 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
         memset(&fsx, 0, sizeof fsx);
         fsx.x = xc; fsx.noise = noise ? wk.noise : nullptr; fsx.coefs = wk.coefs; fsx.step_ptr = step_ptr; fsx.xout = xc;
         fsx.count = countk; fsx.step_off = step_off; fsx.noise_idx = local;
-        return unet_body(m, packed, xc, wk.eps, wk.heads, 0, hstep, step_ptr, step_off, wk, Bk, H, W, st, 0, &fsx);
+        return unet_body(m, packed, xc, wk.eps, wk.heads, 0, hstep, step_ptr, step_off, wk, Bdk, H, W, st, 0, &fsx);
       }
-      if (unet_body(m, packed, xc, wk.eps, wk.heads, 0, hstep, step_ptr, step_off, wk, Bk, H, W, st)) return 1;
+      if (unet_body(m, packed, xc, wk.eps, wk.heads, 0, hstep, step_ptr, step_off, wk, Bdk, H, W, st)) return 1;
       return launch_step(xc, wk.eps, noise ? wk.noise : nullptr, local, wk.coefs, step_ptr, step_off, nullptr, xc, countk, 0, 0.f, st);
     }
-    // doubled batch [x;x] with embeddings [cond ; null] (build-defined CFG; never split: NS = 1, countk = count)
+    // doubled batch [x;x] with embeddings [cond ; null] (build-defined CFG)
     // (when block 0 is evaluated once for both halves, only x itself is read: no duplicate needed)
-    const bool shared = shares_first_layers(m, Bd, H, W, B);
+    const bool shared = shares_first_layers(m, Bdk, H, W, Bk);
     if (!shared) {
-      size_t blocks = (count + 255) / 256;
+      size_t blocks = (countk + 255) / 256;
       if (blocks > 4096) blocks = 4096;
-      hipLaunchKernelGGL(dup_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xc, wk.xx, count);
+      hipLaunchKernelGGL(dup_kernel, dim3((unsigned)blocks), dim3(256), 0, st, xc, wk.xx, countk);
       HIP_TRY(hipGetLastError());
     }
     static const bool no_table = getenv("DM_DEBUG_NO_TEMB_TABLE") != nullptr;  // diagnostics only: the time MLP per entry and step, as before
-    if (launch_time_embed(m, packed, wk.ts, Bd, wk.cond, nullptr, wk.heads, st, step_ptr, step_off, 0, no_table ? nullptr : wk.temb)) return 1;
-    if (unet_body(m, packed, shared ? xc : wk.xx, wk.eps, wk.heads, hstep, 0, nullptr, 0, wk, Bd, H, W, st, B)) return 1;
-    return launch_step(xc, wk.eps, noise ? wk.noise : nullptr, local, wk.coefs, step_ptr, step_off, nullptr, xc, count, 1, guidance, st);
+    if (launch_time_embed(m, packed, wk.ts, Bdk, wk.cond, nullptr, wk.heads, st, step_ptr, step_off, 0, no_table ? nullptr : wk.temb)) return 1;
+    if (unet_body(m, packed, shared ? xc : wk.xx, wk.eps, wk.heads, hstep, 0, nullptr, 0, wk, Bdk, H, W, st, Bk)) return 1;
+    return launch_step(xc, wk.eps, noise ? wk.noise : nullptr, local, wk.coefs, step_ptr, step_off, nullptr, xc, countk, 1, guidance, st);
   };
   // noise of steps [first, first + cnt) -> staging area (noise: [n][count], device or host memory)
   // The chunk callback runs on the calling thread BEFORE the chunk is enqueued (everything before `first` already is): it

@@ -143,3 +143,27 @@ def test_split_batches_are_bit_identical(model, monkeypatch, kind, n, eta, B, sp
     assert torch.equal(got, want)
     # ... and a second call reuses the cached multi-branch graph
     assert torch.equal(smp.sample_from(model, x_T, nz), want)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_split_batches_with_guidance_are_bit_identical(sd, monkeypatch, precision):
+    """Guided sampling (doubled batch [x ; x], build-defined) on parallel branches: every sub-batch is its own doubled batch
+    [x_k ; x_k] with its rows of the conditional and of the null embeddings - bit-identical to the single-branch run, in fp32
+    and on the bf16 path, with per-image labels that differ between the sub-batches."""
+    m = d.UNetMini(image_size=32, precision=precision).eval()
+    m.load_state_dict(sd)
+    d.set_seed(5)
+    cc = d.ClassConditioner(11, m.time_emb_dim)
+    B, n = 8, 7
+    x_T = torch.randn((B, 1, 32, 32), generator=torch.Generator().manual_seed(9))
+    lab = torch.tensor([0, 1, 2, 3, 4, 5, 6, 7])
+    cond, null = cc(lab), cc(torch.tensor([10]))
+    smp = d.DDIMSampler(d.DDPMScheduler(), num_inference_steps=n, eta=0.0)
+    monkeypatch.setenv("DM_SPLIT", "1")
+    want = smp.sample_from(m, x_T, cond_emb=cond, null_emb=null, guidance_scale=2.5)
+    monkeypatch.setenv("DM_SPLIT", "4")
+    got = smp.sample_from(m, x_T, cond_emb=cond, null_emb=null, guidance_scale=2.5)
+    assert torch.isfinite(got).all() and torch.equal(got, want)
+    # the labels matter (a branch reading another branch's embedding rows would still be finite)
+    other = smp.sample_from(m, x_T, cond_emb=cc(lab.flip(0)), null_emb=null, guidance_scale=2.5)
+    assert not torch.equal(other[:4], want[:4])
