@@ -57,10 +57,13 @@ int dm_unet_create(dm_unet** out, int in_channels, int out_channels, int model_c
 int dm_unet_create_ex(dm_unet** out, int in_channels, int out_channels, int model_channels,
                       int time_emb_dim, int attention);
 int dm_unet_num_params(const dm_unet* m);
-/* bf16 != 0: activations between kernels and the packed conv weights are bfloat16, MFMA is
- * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; GroupNorm statistics, the SiLU transform, the
- * time embedding, eps and the sampler update stay fp32 (BASELINE configs[3]; north_star tolerance
- * |eps - eps_fp32| <= 2e-2).  Call BEFORE dm_unet_pack_weights; drops cached graphs. */
+/* bf16 != 0: activations between kernels are 16-bit (bfloat16; IEEE half where the consumer
+ * normalises the tensor), the packed conv weights are bfloat16 (hi, lo) pairs, MFMA is
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation - except the layers behind a GroupNorm in
+ * down1, down2.conv2 and up3, whose operands (activation and ONE weight per product) are IEEE
+ * half on v_mfma_f32_32x32x16_f16; GroupNorm statistics, the SiLU transform, the time embedding,
+ * eps and the sampler update stay fp32 (BASELINE configs[3]; north_star tolerance
+ * |eps - eps_fp32| <= 2e-2, measured <= 0.95e-2).  Call BEFORE dm_unet_pack_weights; drops cached graphs. */
 int dm_unet_set_precision(dm_unet* m, int bf16);
 void dm_unet_destroy(dm_unet* m);
 
@@ -164,7 +167,9 @@ int dm_sample_chunked(dm_unet* m, const float* packed_dev, float* x_dev, int B, 
                       void* workspace_dev, size_t workspace_bytes, int use_graph, void* stream);
 
 /* Workspace bytes dm_sample needs: dm_unet_workspace_bytes for the (doubled when `guided`) batch
- * and an n-step table, plus the staging area for one graph chunk of noise when `with_noise`. */
+ * and an n-step table, plus the staging area for one graph chunk of noise when `with_noise`;
+ * where dm_sample runs the batch as parallel sub-batch chains (B*H*W >= 2^18 pixels with
+ * use_graph, or DM_SPLIT in the environment), one such carve per chain if that is more. */
 size_t dm_sample_workspace_bytes(const dm_unet* m, int B, int H, int W, int n, int guided,
                                  int with_noise);
 
