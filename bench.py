@@ -465,6 +465,25 @@ def main():
         res["rehearsal"] = "CPU plumbing rehearsal (DM_BENCH_REHEARSE_CPU): stand-in sampler, `value` is not a measurement"
         args.no_roofline = args.no_cpu_baseline = args.no_configs = True
 
+    if model is not None:
+        # dm_sample runs large batches as parallel sub-batch chains on branches of the captured graph:
+        # a scheduling decision, bit-identical samples; `single_chain` is the same pass with DM_SPLIT=1 beside it
+        nb = _l.lib().dm_sample_branches(model._native(), B, IMG, IMG, 1 if args.cfg else 0)
+        res["config"]["parallel_branches"] = nb
+        if rank == 0 and world == 1 and nb > 1:
+            prev = os.environ.get("DM_SPLIT")
+            os.environ["DM_SPLIT"] = "1"
+            try:
+                dts, _ = timed_passes(lambda: fn(x_T, None), max(2, args.steps), warm=1)
+            finally:
+                if prev is None:
+                    del os.environ["DM_SPLIT"]
+                else:
+                    os.environ["DM_SPLIT"] = prev
+            res["single_chain"] = {"value": B / dts, "unit": "images/s", "ms_per_step": 1e3 * dts,
+                                   "note": f"the same pass as ONE chain of {B} images (DM_SPLIT=1); `value` runs {nb} chains of {B // nb} images on "
+                                           "parallel branches of the graph. `roofline` / `kernels` time single-chain launches of the whole batch"}
+
     if rank == 0 and world == 1 and not rehearse:
         # end to end: x_T uploaded from (pinned) host memory and the finished samples downloaded inside the timed region
         xh = x_T_host.pin_memory()

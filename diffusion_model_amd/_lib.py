@@ -33,6 +33,7 @@ _SIGS = {
     "dm_sample": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _sz, _i, _vp]),
     "dm_sample_chunked": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _sz, _i, _vp]),
     "dm_sample_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
+    "dm_sample_branches": (_i, [_vp, _i, _i, _i, _i]),
     "dm_sampler_step_batched": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "dm_attention": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "dm_final_conv": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -1615,6 +1615,11 @@ static int sample_split(const dm_unet* m, int B, int H, int W, int guided) {
   return k < 1 ? 1 : k;
 }
 
+int dm_sample_branches(const dm_unet* m, int B, int H, int W, int guided) {
+  if (!m || B <= 0 || H <= 0 || W <= 0) return 0;
+  return sample_split(m, B, H, W, guided);
+}
+
 size_t dm_sample_workspace_bytes(const dm_unet* m, int B, int H, int W, int n, int guided, int with_noise) {
   if (!m || B <= 0 || H <= 0 || W <= 0 || n <= 0) return 0;
   const int S0 = n < 50 ? n : 50;

@@ -173,6 +173,11 @@ int dm_sample_chunked(dm_unet* m, const float* packed_dev, float* x_dev, int B, 
 size_t dm_sample_workspace_bytes(const dm_unet* m, int B, int H, int W, int n, int guided,
                                  int with_noise);
 
+/* Number of parallel sub-batch chains dm_sample / dm_sample_chunked run a batch of B images as when
+ * `use_graph` is set (1 = one chain; the samples are the same bits either way).  No reference
+ * counterpart: the reference's loop (diffusion/sampler.py:45-76) is one chain of B images. */
+int dm_sample_branches(const dm_unet* m, int B, int H, int W, int guided);
+
 /* DDPMScheduler.step with a [B] timestep tensor (diffusion/schedulers.py:113-115: the table
  * lookups become `.view(-1,1,1,1)` per-image coefficients) in ONE launch: coefs_dev float[B][8]
  * (dm_sampler_coefs rows, uploaded), count_per_image = C*H*W elements; noise_dev NULL or

@@ -167,3 +167,28 @@ def test_split_batches_with_guidance_are_bit_identical(sd, monkeypatch, precisio
     # the labels matter (a branch reading another branch's embedding rows would still be finite)
     other = smp.sample_from(m, x_T, cond_emb=cc(lab.flip(0)), null_emb=null, guidance_scale=2.5)
     assert not torch.equal(other[:4], want[:4])
+
+
+def test_split_batches_on_the_any_geometry_path_are_bit_identical(monkeypatch):
+    """The parallel branches on the any-geometry kernels (24x24x3 images, 40 channels: stand-alone GroupNorm passes, gconv)."""
+    d.set_seed(11)
+    m = d.UNetMini(image_size=24, in_channels=3, out_channels=3, model_channels=40).eval()
+    x_T = torch.randn((6, 3, 24, 24), generator=torch.Generator().manual_seed(2))
+    smp = d.DDIMSampler(d.DDPMScheduler(), num_inference_steps=6, eta=0.0)
+    monkeypatch.setenv("DM_SPLIT", "1")
+    want = smp.sample_from(m, x_T)
+    monkeypatch.setenv("DM_SPLIT", "3")
+    assert torch.equal(smp.sample_from(m, x_T), want)
+
+
+def test_sample_branches_entry_point(model):
+    """dm_sample_branches: what dm_sample will do with a batch (bench.py reports it): one chain below 2^18 pixels, four above,
+    fewer where four do not divide the batch; DM_SPLIT overrides."""
+    L = _lib.lib()
+    h = model._native()
+    assert L.dm_sample_branches(h, 64, 32, 32, 0) == 1
+    assert L.dm_sample_branches(h, 255, 32, 32, 0) == 1
+    assert L.dm_sample_branches(h, 1024, 32, 32, 0) == 4 and L.dm_sample_branches(h, 1024, 32, 32, 1) == 4
+    assert L.dm_sample_branches(h, 1023, 32, 32, 0) == 3 and L.dm_sample_branches(h, 1021, 32, 32, 0) == 1
+    assert L.dm_sample_branches(h, 64, 64, 64, 0) == 4
+    assert L.dm_sample_branches(None, 64, 64, 64, 0) == 0

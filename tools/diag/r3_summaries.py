@@ -85,7 +85,7 @@ for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
 classes = by_class(summary, "launches", ["avg_us"])
 cfg2 = bench_line("prof_cfg2.json")
 dom = cfg2["roofline"]["class"]
-out = {"source": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs "
+out = {"source": "DM_SPLIT=1 (one sampling chain: a launch covers the whole batch, as in bench.py's per-class pass) rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs "
                  "(tools/diag/r3_profiles.sh stats; DDIM-50, B=1024, fp32): per-kernel durations from the kernel trace, every launch of "
                  "the run (warm-up, timed passes and bench.py's per-class profiling pass)",
        "build_key": cfg2["build_key"], "dominant_class": dom, "bench_line_avg_launch_us_same_run": cfg2["roofline"]["avg_launch_us"],
@@ -115,7 +115,7 @@ for k in sorted(f):
     tper[k] = {"launches": len(f[k]), "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
     print(f"{k:44s} {len(f[k]):5d}  read {rd/1e6:8.1f} MB  write {wr/1e6:8.1f} MB")
 tcls = by_class(tper, "launches", ["hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch", "hbm_bytes_per_launch"])
-json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs: tools/diag/r3_profiles.sh traffic) -- python3 "
+json.dump({"source": "DM_SPLIT=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs: tools/diag/r3_profiles.sh traffic) -- python3 "
                      "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-configs (DDIM-50, B=1024, fp32); FETCH_SIZE doubled "
                      "(gfx950 tallies 128-B requests as 64 B), KiB -> bytes; `classes`: launch-weighted per kernel class of bench.py",
            "build_key": bench_line("pmc_fetch.json")["build_key"], "classes": tcls, "per_kernel": tper},
@@ -157,7 +157,7 @@ for tag in ("model", "cfg1"):
         print(f"{tag:6s} {k:44s} n={r['launches']:5d} {r['avg_us_under_pmc']:8.1f} us  busy {100*(r['mfma_busy_frac_of_simd_cycles'] or 0):5.1f}%  "
               f"valu/mfma {r['valu_non_mfma_per_mfma'] or 0:5.2f}  clk {r['kernel_clock_ghz_grbm'] or 0:4.2f} GHz")
     cmd = ("DDIM-50, B=1024, fp32" if tag == "model" else "ancestral, first 100 of 1000 steps, B=64, fp32")
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES "
+    json.dump({"source": "DM_SPLIT=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES "
                          "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE (tools/diag/r3_profiles.sh sq; one bench pass, " + cmd + "); all launches of a kernel summed; "
                          "busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)",
                "build_key": bench_line(d + ".json")["build_key"], "per_kernel": res},
