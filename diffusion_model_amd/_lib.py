@@ -34,6 +34,8 @@ _SIGS = {
     "dm_sample_chunked": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _sz, _i, _vp]),
     "dm_sample_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
     "dm_sample_branches": (_i, [_vp, _i, _i, _i, _i]),
+    "dm_stream_create": (_i, [C.POINTER(_vp)]),
+    "dm_stream_destroy": (_i, [_vp]),
     "dm_sampler_step_batched": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "dm_attention": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "dm_final_conv": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -86,3 +88,14 @@ def check(rc):
 def ptr(t):
     """Device/host pointer of a tensor (None -> NULL)."""
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def own_stream(device):
+    """A torch stream object over a HIP stream of this library's own (dm_stream_create), one per call, never released:
+    torch.cuda.Stream() cycles through a POOL of 32 shared streams per device, so a pooled stream can be the stream some
+    other component launches into - fatal for a stream that is being captured into a hipGraph."""
+    import torch
+    h = _vp()
+    with torch.cuda.device(device):
+        check(lib().dm_stream_create(C.byref(h)))
+    return torch.cuda.ExternalStream(h.value, device=device)

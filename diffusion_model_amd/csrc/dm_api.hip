@@ -1615,6 +1615,20 @@ static int sample_split(const dm_unet* m, int B, int H, int W, int guided) {
   return k < 1 ? 1 : k;
 }
 
+int dm_stream_create(void** stream_out) {
+  if (!stream_out) return fail("dm_stream_create: null argument");
+  hipStream_t st = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *stream_out = st;
+  return 0;
+}
+
+int dm_stream_destroy(void* stream) {
+  if (!stream) return 0;
+  HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+
 int dm_sample_branches(const dm_unet* m, int B, int H, int W, int guided) {
   if (!m || B <= 0 || H <= 0 || W <= 0) return 0;
   return sample_split(m, B, H, W, guided);
@@ -1891,7 +1905,9 @@ void dm_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
 void dm_debug_lowres_taps(float* taps_dev) { g_lowres_taps = taps_dev; }
 
 // tests: the maxima buffers of the NEXT dm_conv2d call (kinds 13-15; see ConvArgs.amax1 / amax_out), cleared by that call
-static const float* g_dbg_amax1 = nullptr; static const float* g_dbg_amax2 = nullptr; static int g_dbg_n1 = 0, g_dbg_n2 = 0; static float* g_dbg_amax_out = nullptr;
+// (per thread: a dm_conv2d call of ANOTHER thread - the test suite's co-runner - must not consume them)
+static thread_local const float* g_dbg_amax1 = nullptr; static thread_local const float* g_dbg_amax2 = nullptr;
+static thread_local int g_dbg_n1 = 0, g_dbg_n2 = 0; static thread_local float* g_dbg_amax_out = nullptr;
 void dm_debug_conv_amax(const float* amax1, int namax1, const float* amax2, int namax2, float* amax_out) {
   g_dbg_amax1 = amax1; g_dbg_n1 = namax1; g_dbg_amax2 = amax2; g_dbg_n2 = namax2; g_dbg_amax_out = amax_out;
 }

@@ -188,10 +188,12 @@ _SIDE = {}
 
 
 def _side_stream(dev):
-    """hipGraph capture is illegal on the legacy default stream: the loop runs on a side stream."""
+    """hipGraph capture is illegal on the legacy default stream: the loop runs on a side stream - one of the library's own
+    per device (_lib.own_stream), not one of torch's 32 pooled streams, which another component's torch.cuda.Stream() may
+    alias: a launch into it from another thread during the capture would invalidate the graph."""
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=dev)
+        _SIDE[key] = _lib.own_stream(torch.device("cuda", key[1]))
     return _SIDE[key]
 
 

@@ -173,6 +173,13 @@ int dm_sample_chunked(dm_unet* m, const float* packed_dev, float* x_dev, int B, 
 size_t dm_sample_workspace_bytes(const dm_unet* m, int B, int H, int W, int n, int guided,
                                  int with_noise);
 
+/* A non-blocking HIP stream of the caller's own on the current device (hipStreamCreateWithFlags), and its release.
+ * No reference counterpart.  For hosts whose framework hands out POOLED streams: torch.cuda.Stream() cycles through 32
+ * shared streams per device, so a pooled stream used for graph capture can be the very stream another component (another
+ * thread) launches into, which invalidates the capture; the Python samplers capture on a stream from here. */
+int dm_stream_create(void** stream_out);
+int dm_stream_destroy(void* stream);
+
 /* Number of parallel sub-batch chains dm_sample / dm_sample_chunked run a batch of B images as when
  * `use_graph` is set (1 = one chain; the samples are the same bits either way).  No reference
  * counterpart: the reference's loop (diffusion/sampler.py:45-76) is one chain of B images. */

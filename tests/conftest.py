@@ -29,6 +29,9 @@ def sd(ckpt):
     return ckpt["model_state_dict"]
 
 
+_CORUN_STREAM = None
+
+
 @pytest.fixture(autouse=True)
 def _co_runner(request):
     """Opt-in (DM_TEST_CORUN=1): every GPU test runs while a second stream keeps the bf16 matrix pipe busy with the library's
@@ -41,7 +44,12 @@ def _co_runner(request):
     from diffusion_model_amd import _lib
     L = _lib.lib()
     dev = "cuda"
-    s2 = torch.cuda.Stream()
+    # (a stream of its own: torch.cuda.Stream() cycles through 32 pooled streams and, a few dozen tests in, hands out one that a
+    #  test is capturing a graph on - the co-runner's launches then land INSIDE that capture)
+    global _CORUN_STREAM
+    if _CORUN_STREAM is None:
+        _CORUN_STREAM = _lib.own_stream(torch.device("cuda", torch.cuda.current_device()))
+    s2 = _CORUN_STREAM
     with torch.cuda.stream(s2):
         xa = torch.randn(32, 16, 16, 64, device=dev)
         wa = (torch.randn(64, 64, 4, 4, device=dev) * 0.05).contiguous()
