@@ -1043,8 +1043,9 @@ int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float
   const BlockOff &d2b = m->blk[1], &d3 = m->blk[2], &u1 = m->blk[3], &u2b = m->blk[4];
   // fp32 path: two fp16 terms per operand (*h packs; DM_X6 bit 7) or the three-term split-bf16 packs (*x); bf16 path: the
   // (hi, lo) pair packs - the same order, two terms
-  const bool bf = m->bf16 != 0;
-  const bool hf = !bf && (m->x6 & 128);
+  const bool bh = m->bf16 != 0 && m->bf_h == 2;   // bf16 path, one half term per operand (lowres_fused_kernel<4>): the *h packs' first plane
+  const bool bf = m->bf16 != 0 && !bh;            // bf16 path, bf16 operands with (hi, lo) weight pairs (<1>)
+  const bool hf = bh || (!m->bf16 && (m->x6 & 128));
   const size_t C = (size_t)m->C, n3 = hf ? 9 * C * C : 0, n3c = 2 * n3, n4 = hf ? 16 * C * C : 0;
   a.t2 = t2; a.st2 = st2; a.pin2 = pin2; a.cnt2 = cnt2; a.g2 = P + d2b.g2; a.b2 = P + d2b.b2;
   a.d2t = layer(bf ? d2b.tr : hf ? d2b.trh : d2b.trx, d2b.trb, 0, 0, false, -1, n4);
@@ -1072,13 +1073,15 @@ int launch_lowres(const dm_unet* m, const float* P, const float* t2, const float
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_fused_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lowres_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done[dev] = true;
   }
   unsigned grid = 2u * cu_count(dev);  // persistent: two workgroups per CU (60 KB of LDS each), images n, n + grid, ...
   if (grid > (unsigned)B) grid = (unsigned)B;
   // algorithmic work of the twelve layers: 25,231,360 multiply-adds per image
   ProfScope ps(DM_K_LOWRES, s, 2.0 * 25231360.0 * B, 4.0 * B * (2.0 * 16 * 16 * 64 + 2.0 * 8 * 8 * 64) + 6.0 * 12.6 * 64 * 64 * 9);
-  if (bf) hipLaunchKernelGGL(lowres_fused_kernel<1>, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
+  if (bh) hipLaunchKernelGGL(lowres_fused_kernel<4>, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
+  else if (bf) hipLaunchKernelGGL(lowres_fused_kernel<1>, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
   else if (hf) hipLaunchKernelGGL(lowres_fused_kernel<2>, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
   else hipLaunchKernelGGL(lowres_fused_kernel<3>, dim3(grid), dim3(256), (size_t)lr::LDS_BYTES, s, a);
   HIP_TRY(hipGetLastError());
@@ -1470,6 +1473,7 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
       copy(m->o_tm2w, p[i++], (size_t)E * E) || copy(m->o_tm2b, p[i++], E) ||
       copy(m->o_initw, p[i++], (size_t)C * m->Cin * 9) || copy(m->o_initb, p[i++], C)) return 1;
   const bool xf = m->fast && !m->bf16;  // Winograd / split-bf16 weight forms (fp32 tuned kernels)
+  const bool hpk = xf || (m->fast && m->bf16 && m->bf_h == 2);  // two-fp16-term packs (bf16 path: the fused low-resolution kernel reads their first plane)
   if (m->fast) {  // init_conv o down1.conv1 as one 5x5 convolution (dm_kernels_init5.hip): p[4], p[5] = init_conv, p[8], p[9] = down1.conv1
     const size_t n1 = (size_t)9 * (25 * m->Cin + 1) * C;
     hipLaunchKernelGGL(pack_init5_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, p[4], p[5], p[8], p[9], m->Cin, C,
@@ -1480,21 +1484,22 @@ int dm_unet_pack_weights(dm_unet* m, const float* const* p, int nparams, const f
     const bool up = k >= 3;
     const BlockOff& b = m->blk[k];
     if (copy(b.tmw, p[i++], (size_t)C * E) || copy(b.tmb, p[i++], C)) return 1;
-    if (xf && (pack_conv(5, p[i], up ? 2 * C : C, C, packed + b.c1w, s) || pack_conv(7, p[i], up ? 2 * C : C, C, packed + b.c1x, s) ||
-               pack_conv(15, p[i], up ? 2 * C : C, C, packed + b.c1h, s))) return 1;
+    if (xf && (pack_conv(5, p[i], up ? 2 * C : C, C, packed + b.c1w, s) || pack_conv(7, p[i], up ? 2 * C : C, C, packed + b.c1x, s))) return 1;
+    if (hpk && pack_conv(15, p[i], up ? 2 * C : C, C, packed + b.c1h, s)) return 1;
     if (pack_conv(0, p[i++], up ? 2 * C : C, C, packed + b.c1, s, m->bf16) || copy(b.c1b, p[i++], C)) return 1;
-    if (xf && (pack_conv(up ? 9 : 8, p[i], C, C, packed + b.trx, s) || pack_conv(up ? 14 : 13, p[i], C, C, packed + b.trh, s))) return 1;
+    if (xf && pack_conv(up ? 9 : 8, p[i], C, C, packed + b.trx, s)) return 1;
+    if (hpk && pack_conv(up ? 14 : 13, p[i], C, C, packed + b.trh, s)) return 1;
     if (pack_conv(up ? 2 : 1, p[i++], C, C, packed + b.tr, s, bf_half_layer(m, k, 1) ? 2 : m->bf16) || copy(b.trb, p[i++], C)) return 1;
-    if (xf && (pack_conv(5, p[i], C, C, packed + b.c2w, s) || pack_conv(7, p[i], C, C, packed + b.c2x, s) ||
-               pack_conv(15, p[i], C, C, packed + b.c2h, s))) return 1;
+    if (xf && (pack_conv(5, p[i], C, C, packed + b.c2w, s) || pack_conv(7, p[i], C, C, packed + b.c2x, s))) return 1;
+    if (hpk && pack_conv(15, p[i], C, C, packed + b.c2h, s)) return 1;
     if (pack_conv(0, p[i++], C, C, packed + b.c2, s, bf_half_layer(m, k, 2) ? 2 : m->bf16) || copy(b.c2b, p[i++], C)) return 1;
     if (copy(b.g1, p[i++], C) || copy(b.b1, p[i++], C) || copy(b.g2, p[i++], C) || copy(b.b2, p[i++], C)) return 1;
     return 0;
   };
   for (int k = 0; k < 3; ++k) if (do_block(k)) return 1;
   if (xf && (pack_conv(5, p[i], C, C, packed + m->o_b0w, s) || pack_conv(5, p[i + 4], C, C, packed + m->o_b3w, s) ||
-                   pack_conv(7, p[i], C, C, packed + m->o_b0x, s) || pack_conv(7, p[i + 4], C, C, packed + m->o_b3x, s) ||
-                   pack_conv(15, p[i], C, C, packed + m->o_b0h, s) || pack_conv(15, p[i + 4], C, C, packed + m->o_b3h, s))) return 1;
+                   pack_conv(7, p[i], C, C, packed + m->o_b0x, s) || pack_conv(7, p[i + 4], C, C, packed + m->o_b3x, s))) return 1;
+  if (hpk && (pack_conv(15, p[i], C, C, packed + m->o_b0h, s) || pack_conv(15, p[i + 4], C, C, packed + m->o_b3h, s))) return 1;
   if (pack_conv(0, p[i++], C, C, packed + m->o_b0, s, m->bf16) || copy(m->o_b0b, p[i++], C) ||
       copy(m->o_bg, p[i++], C) || copy(m->o_bb, p[i++], C) ||
       pack_conv(0, p[i++], C, C, packed + m->o_b3, s, m->bf16) || copy(m->o_b3b, p[i++], C)) return 1;

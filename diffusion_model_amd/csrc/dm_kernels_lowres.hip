@@ -27,7 +27,11 @@
 // first two terms of the same packing -, two MFMAs per product; input as IEEE half, output as bf16 like the layer kernels.
 // Chosen by the layer geometry only (C = 64, 32x32 images, fp32, no attention), never by the batch size: per-image results
 // do not depend on the batch an image rides in, so multi-GPU shards stay bit-identical to the unsharded run.
+// NA = 4 is the bf16 path's default form since round 3 (DM_BF16_F16 = 2): ONE IEEE-half activation plane and ONE half weight
+// per product (the first plane of the two-fp16-term packs), one v_mfma_f32_32x32x16_f16 per product; raw tensors scaled by a
+// power of two as for NA = 2, 16-bit input / output as for NA = 1.
 #pragma once
+#include "dm_kernels_bf16.hip"
 #include "dm_kernels_x6.hip"
 
 struct LrLayer {
@@ -104,10 +108,17 @@ typedef float lr_f32x4 __attribute__((ext_vector_type(4)));
 struct WS { const bf16_t* wp; size_t ts, so; };
 struct WFrag { uint4 q[4][3]; };  // the three split terms of the four 16-channel slabs of one tap
 
+// what a form NA means: activation planes in LDS, weight terms fetched per fragment, fp16 operands with power-of-two scales
+// (weight packs and raw tensors), 16-bit tensors at the kernel's boundary
+constexpr int lr_planes(int NA) { return NA == 4 ? 1 : NA; }
+constexpr int lr_wterms(int NA) { return NA == 3 ? 3 : NA == 4 ? 1 : 2; }
+constexpr bool lr_scaled(int NA) { return NA == 2 || NA == 4; }
+constexpr bool lr_io16(int NA) { return NA == 1 || NA == 4; }
+
 // fetch the fragments of packed tap wt (L2): issued a whole layer epilogue ahead of their first use
 template <int NA, int NJ = 4>
 __device__ __forceinline__ void kload(WFrag& f, const WS& w, int wt, unsigned lane16) {
-  constexpr int NB = NA == 3 ? 3 : 2;  // weight terms: three-way split (fp32 path) / (hi, lo) pair (bf16 path)
+  constexpr int NB = lr_wterms(NA);  // weight terms: three-way split / two fp16 terms (fp32 path), (hi, lo) pair / one half (bf16 path)
   int opq = 0;
   asm volatile("" : "+v"(opq));  // (the address arithmetic stays here: see krun)
   lane16 += (unsigned)opq;
@@ -137,7 +148,7 @@ __device__ __forceinline__ void krun(f32x16& acc, WFrag& f, const bf16_t* ap, in
   int aoff, wt;
   tapf(0, aoff, wt);
 #pragma unroll
-  for (int s = 0; s < NA; ++s) a[0][s] = *reinterpret_cast<const uint4*>(ap + s * pl + aoff);
+  for (int s = 0; s < lr_planes(NA); ++s) a[0][s] = *reinterpret_cast<const uint4*>(ap + s * pl + aoff);
 #pragma unroll 1
   for (int t = 0; t < ntaps; ++t) {
     int aoffn, wtn;
@@ -181,6 +192,10 @@ __device__ __forceinline__ void krun(f32x16& acc, WFrag& f, const bf16_t* ap, in
         __builtin_amdgcn_sched_barrier(0);
         acc = dm_mfma16<true>(f.q[j][0], a[c][0], acc);
         f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+      } else if constexpr (NA == 4) {  // one half term each
+        acc = dm_mfma16<true>(f.q[j][0], a[c][0], acc);
+        a[nx][0] = *reinterpret_cast<const uint4*>(an);
+        f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
       } else {  // bf16 activations x (hi, lo) weights: a1 lo, then a1 hi
         LR_MFMA(b2, a1, acc, j & 1);
         a[nx][0] = *reinterpret_cast<const uint4*>(an);
@@ -213,7 +228,7 @@ __device__ __forceinline__ void krun2(f32x16& acc0, f32x16& acc1, WFrag& f, cons
   int aoff, wt;
   tapf(0, aoff, wt);
 #pragma unroll
-  for (int s = 0; s < NA; ++s) {
+  for (int s = 0; s < lr_planes(NA); ++s) {
     a[0][0][s] = *reinterpret_cast<const uint4*>(ap0 + s * pl + aoff);
     a[0][1][s] = *reinterpret_cast<const uint4*>(ap1 + s * pl + aoff);
   }
@@ -283,6 +298,13 @@ __device__ __forceinline__ void krun2(f32x16& acc0, f32x16& acc1, WFrag& f, cons
         acc0 = dm_mfma16<true>(f.q[j][0], a[c][0][0], acc0);
         __builtin_amdgcn_sched_barrier(0);
         acc1 = dm_mfma16<true>(f.q[j][0], a[c][1][0], acc1);
+        f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
+      } else if constexpr (NA == 4) {  // one half term each; block 0 then block 1
+        acc0 = dm_mfma16<true>(f.q[j][0], a[c][0][0], acc0);
+        a[nx][0][0] = *reinterpret_cast<const uint4*>(an0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc1 = dm_mfma16<true>(f.q[j][0], a[c][1][0], acc1);
+        a[nx][1][0] = *reinterpret_cast<const uint4*>(an1);
         f.q[j][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnext + (size_t)j * JS) + lane16);
       } else {  // bf16 activations x (hi, lo) weights
         LR_MFMA(b2, p1, acc0, j & 1);
@@ -459,6 +481,13 @@ __device__ __forceinline__ void put_planes(const f32x16& acc, bf16_t* buf, int p
       *reinterpret_cast<uint2*>(q + 8 * k + pl) = s2;
       continue;
     }
+    if constexpr (NA == 4) {  // one half plane of the values times sc, to nearest even
+      uint2 s1;
+      s1.x = bf_pack_h2(acc[4 * k] * sc, acc[4 * k + 1] * sc);
+      s1.y = bf_pack_h2(acc[4 * k + 2] * sc, acc[4 * k + 3] * sc);
+      *reinterpret_cast<uint2*>(q + 8 * k) = s1;
+      continue;
+    }
     if constexpr (NA == 1) {  // one plane: round to nearest even
       uint2 s1;
       s1.x = (unsigned)f2bf(acc[4 * k]) | ((unsigned)f2bf(acc[4 * k + 1]) << 16);
@@ -486,6 +515,13 @@ __device__ __forceinline__ void put_planes8(float4 w0, float4 w1, bf16_t* q, int
     dm_split_h2(w1.z * sc, w1.w * sc, s1.w, s2.w);
     *reinterpret_cast<uint4*>(q) = s1;
     *reinterpret_cast<uint4*>(q + pl) = s2;
+    return;
+  }
+  if constexpr (NA == 4) {
+    uint4 s1;
+    s1.x = bf_pack_h2(w0.x * sc, w0.y * sc); s1.y = bf_pack_h2(w0.z * sc, w0.w * sc);
+    s1.z = bf_pack_h2(w1.x * sc, w1.y * sc); s1.w = bf_pack_h2(w1.z * sc, w1.w * sc);
+    *reinterpret_cast<uint4*>(q) = s1;
     return;
   }
   if constexpr (NA == 1) {
@@ -525,8 +561,9 @@ __device__ __forceinline__ void put_f32(const f32x16& acc, float* q) {
 // zero the given pixel rows (all three planes) of a plane buffer: idx -> pixel index through f
 template <int NA, class F>
 __device__ __forceinline__ void zero_pixels(bf16_t* buf, int pl, int npix, F pixf) {
-  for (int i = threadIdx.x; i < npix * 9 * NA; i += 256) {  // NA planes x 9 uint4 per pixel row
-    const int pp = i / (9 * NA), r = i - pp * (9 * NA), s = r / 9, u = r - s * 9;
+  constexpr int NPL = lr_planes(NA);
+  for (int i = threadIdx.x; i < npix * 9 * NPL; i += 256) {  // planes x 9 uint4 per pixel row
+    const int pp = i / (9 * NPL), r = i - pp * (9 * NPL), s = r / 9, u = r - s * 9;
     *reinterpret_cast<uint4*>(buf + s * pl + pixf(pp) * RSB + u * 8) = make_uint4(0u, 0u, 0u, 0u);
   }
 }
@@ -589,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     const LrLayer* Ls[12] = {&p.d2t, &p.d3c1, &p.d3c2, &p.d3t, &p.b0, &p.b3, &p.u1c1, &p.u1c2, &p.u1t, &p.u2c1, &p.u2c2, &p.u2t};
     float v = 1.f;
 #pragma unroll
-    for (int l = 0; l < 12; ++l) if (l == tid && NA == 2) v = *Ls[l]->wsc;
+    for (int l = 0; l < 12; ++l) if (l == tid && lr_scaled(NA)) v = *Ls[l]->wsc;
     sm[SM_WSC + tid] = v;   // (1 where the pack carries no scale)
   }
   const float* bias_t = sm + SM_BIAS;
@@ -659,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
         const int iy = 2 * Y - pa, ix = 2 * Xc - pb;
         inbm |= ((unsigned)iy < 16u && (unsigned)ix < 16u) ? (1u << u) : 0u;
         const int eo = (min(max(iy, 0), 15) * 16 + min(max(ix, 0), 15)) * 64 + c8 * 8;
-        if constexpr (NA == 1) {
+        if constexpr (lr_io16(NA)) {
           v0[u] = __builtin_bit_cast(float4, *reinterpret_cast<const uint4*>(srch + eo));  // eight halves, widened when staged
         } else {
           v0[u] = *reinterpret_cast<const float4*>(src + eo);
@@ -677,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
         if (idx < 81 * 8) {
           const int pix = idx >> 3, c8 = idx & 7;
           float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
-          if constexpr (NA == 1) {
+          if constexpr (lr_io16(NA)) {
             const uint4 hv = __builtin_bit_cast(uint4, v0[u]);
             v0[u] = make_float4(h2f((bf16_t)(hv.x & 0xffff)), h2f((bf16_t)(hv.x >> 16)), h2f((bf16_t)(hv.y & 0xffff)), h2f((bf16_t)(hv.y >> 16)));
             v1[u] = make_float4(h2f((bf16_t)(hv.z & 0xffff)), h2f((bf16_t)(hv.z >> 16)), h2f((bf16_t)(hv.w & 0xffff)), h2f((bf16_t)(hv.w >> 16)));
@@ -703,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     put_f32(acc, p.d2 + ((size_t)n * 64 + m8) * 64 + cb);  // down2's output, raw: skip input of up2.conv1, read back by this workgroup
     zero_ring<NA, 10>(P, PL);
     float s_d2 = 1.f, i_d2 = 1.f;   // power-of-two scale of down2's output as planes (NA = 2), and its inverse
-    if constexpr (NA == 2) s_d2 = wg_scale(lane_amax(acc), red4, wave, i_d2);
+    if constexpr (lr_scaled(NA)) s_d2 = wg_scale(lane_amax(acc), red4, wave, i_d2);
     put_planes<NA>(acc, P, PL, (y8 + 1) * 10 + x8 + 1, cb, s_d2);  // ... and, as planes, the input of down3.conv1
 
     LR_STAMP(1);
@@ -771,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       scale_bias(acc, wsc[3], bias_t + 3 * 64, cb);
     }
     float s_d3 = 1.f, i_d3 = 1.f;   // scale of down3's output as planes
-    if constexpr (NA == 2) s_d3 = wg_scale((!wm && v4) ? lane_amax(acc) : 0.f, red4, wave, i_d3);
+    if constexpr (lr_scaled(NA)) s_d3 = wg_scale((!wm && v4) ? lane_amax(acc) : 0.f, red4, wave, i_d3);
     if (!wm) {
       if (v4) put_planes<NA>(acc, D3p, PL4, pix6, cb, s_d3);  // down3's output, raw: input of bottleneck.0 and skip input of up1.conv1
       if (p.taps && v4) put_f32(acc, p.taps + (size_t)n * 6144 + m4 * 64 + cb);
@@ -807,7 +844,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
         if (ni >= 0) gn_silu_regs<1>(acc, v4, 1.0f / 128.0f, sm + SM_GAMMA + ni * 64, sm + SM_BETA + ni * 64, temb, cb, red, wave, wn);
       }
       s_out = 1.f; i_out = 1.f;
-      if constexpr (NA == 2) if (ni < 0) s_out = wg_scale((!wm && v4) ? lane_amax(acc) : 0.f, red4, wave, i_out);
+      if constexpr (lr_scaled(NA)) if (ni < 0) s_out = wg_scale((!wm && v4) ? lane_amax(acc) : 0.f, red4, wave, i_out);
       if (!wm) {
         if (v4) put_planes<NA>(acc, out, PL4, pix6, cb, s_out);
         if (tap_off >= 0 && p.taps && v4) put_f32(acc, p.taps + (size_t)n * 6144 + tap_off + m4 * 64 + cb);
@@ -843,7 +880,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
       put_f32(acc1, p.taps + (size_t)n * 6144 + 2048 + ((2 * y4 + wm) * 8 + 2 * x4 + 1) * 64 + cb);
     }
     float s_u1 = 1.f, i_u1 = 1.f;   // scale of up1's output as planes
-    if constexpr (NA == 2) s_u1 = wg_scale(v4 ? fmaxf(lane_amax(acc), lane_amax(acc1)) : 0.f, red4, wave, i_u1);
+    if constexpr (lr_scaled(NA)) s_u1 = wg_scale(v4 ? fmaxf(lane_amax(acc), lane_amax(acc1)) : 0.f, red4, wave, i_u1);
     else __syncthreads();  // every wave is done with F: P becomes the 10x10 layout again (NA = 2: wg_scale's barrier)
     zero_ring<NA, 10>(P, PL);
     if (v4) {  // up1's output, raw: first input of up2.conv1 (parity py = wm, px = 0 / 1)
@@ -866,7 +903,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
     }
     krun2<NA, 2>(acc, acc1, wf, a8a, a8b, PL, w_u2c1a, lane16, 9, tap3_10);
     kload<NA, 2>(wf, w_u2c1b, 0, lane16);
-    if constexpr (NA == 2) {  // the sums over up1's channels move to the scale of down2's planes (powers of two: exact)
+    if constexpr (lr_scaled(NA)) {  // the sums over up1's channels move to the scale of down2's planes (powers of two: exact)
       const float rs = i_u1 * s_d2;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[r] *= rs; acc1[r] *= rs; }
@@ -916,7 +953,7 @@ __global__ __launch_bounds__(256, 2) void lowres_fused_kernel(const LowresArgs p
         if (p.amax_u2) amx = fmaxf(amx, fmaxf(lane_amax(acc), lane_amax(acc1)));
         const size_t oa = (((size_t)n * 16 + 2 * y8a + py) * 16 + 2 * x8l + px) * 64 + cb;
         const size_t ob = (((size_t)n * 16 + 2 * y8b + py) * 16 + 2 * x8l + px) * 64 + cb;
-        if constexpr (NA == 1) {
+        if constexpr (lr_io16(NA)) {
           put_bf16(acc, reinterpret_cast<bf16_t*>(p.u2) + oa);
           put_bf16(acc1, reinterpret_cast<bf16_t*>(p.u2) + ob);
         } else {
