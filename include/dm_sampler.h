@@ -60,10 +60,11 @@ int dm_unet_num_params(const dm_unet* m);
 /* bf16 != 0: activations between kernels are 16-bit (bfloat16; IEEE half where the consumer
  * normalises the tensor), the packed conv weights are bfloat16 (hi, lo) pairs, MFMA is
  * v_mfma_f32_32x32x16_bf16 with fp32 accumulation - except the layers behind a GroupNorm in
- * down1, down2.conv2 and up3, whose operands (activation and ONE weight per product) are IEEE
- * half on v_mfma_f32_32x32x16_f16; GroupNorm statistics, the SiLU transform, the time embedding,
- * eps and the sampler update stay fp32 (BASELINE configs[3]; north_star tolerance
- * |eps - eps_fp32| <= 2e-2, measured <= 0.95e-2).  Call BEFORE dm_unet_pack_weights; drops cached graphs. */
+ * down1, down2.conv2 and up3 and the fused low-resolution kernel (raw tensors scaled by a power
+ * of two there), whose operands (activation and ONE weight per product) are IEEE half on
+ * v_mfma_f32_32x32x16_f16; GroupNorm statistics, the SiLU transform, the time embedding, eps and
+ * the sampler update stay fp32 (BASELINE configs[3]; north_star tolerance
+ * |eps - eps_fp32| <= 2e-2, measured <= 0.66e-2).  Call BEFORE dm_unet_pack_weights; drops cached graphs. */
 int dm_unet_set_precision(dm_unet* m, int bf16);
 void dm_unet_destroy(dm_unet* m);
 
