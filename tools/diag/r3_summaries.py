@@ -72,6 +72,14 @@ for cfg in ("cfg1", "cfg2", "cfg4", "cfg5"):
     keys.add(j["build_key"])
     json.dump(j, open(os.path.join(DST, f"r3_{cfg}_bench_profiled.json"), "w"), indent=1)
 
+# ---- the DEFAULT scheduling of the cfg2 command (four sub-batch chains on parallel graph branches; r3_profiles.sh stats4), for the record:
+#      launches cover a quarter of the batch and overlap each other, so their durations are not a kernel's own time
+if glob.glob(os.path.join(SRC, "prof_cfg2_split4/*/*kernel_stats.csv")):
+    shutil.copy(one("prof_cfg2_split4/*/*kernel_stats.csv"), os.path.join(DST, "r3_cfg2_kernel_stats_split4.csv"))
+    j = bench_line("prof_cfg2_split4.json")
+    keys.add(j["build_key"])
+    json.dump(j, open(os.path.join(DST, "r3_cfg2_bench_profiled_split4.json"), "w"), indent=1)
+
 # ---- class average of the dominant kernel by rocprof (cfg2 command), steady launches only
 rows = list(csv.DictReader(open(one("prof_cfg2/*/*kernel_trace.csv"))))
 per = collections.defaultdict(list)
