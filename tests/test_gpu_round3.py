@@ -192,3 +192,22 @@ def test_sample_branches_entry_point(model):
     assert L.dm_sample_branches(h, 1023, 32, 32, 0) == 3 and L.dm_sample_branches(h, 1021, 32, 32, 0) == 1
     assert L.dm_sample_branches(h, 64, 64, 64, 0) == 4
     assert L.dm_sample_branches(None, 64, 64, 64, 0) == 0
+
+
+def test_call_with_chunk_drawn_noise_on_parallel_branches(model, monkeypatch):
+    """`sampler(model, shape)` at a batch the library splits (256 images -> 4 chains): the noise is drawn chunk by chunk into
+    pinned host buffers inside the chunk callback and every branch copies ITS columns of the chunk (a strided 2-D copy from host
+    memory) - equal, bit for bit, to the single-chain loop fed with one up-front draw from the same generator state."""
+    sched = d.DDPMScheduler()
+    smp = d.AncestralSampler(sched, num_inference_steps=1000, eta=1.0)
+    n, shape = 60, (256, 1, 32, 32)
+    sched.timesteps = sched.timesteps[:n]
+    assert _lib.lib().dm_sample_branches(model._native(), 256, 32, 32, 0) == 4
+    torch.manual_seed(123)
+    got = smp(model, shape, progress_bar=False)
+    torch.manual_seed(123)
+    x_T = torch.randn(shape)
+    nz = torch.randn((n,) + shape)
+    monkeypatch.setenv("DM_SPLIT", "1")
+    want = smp.sample_from(model, x_T, nz)
+    assert torch.isfinite(got).all() and torch.equal(got.cpu(), want.cpu())
