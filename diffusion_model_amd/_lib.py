@@ -56,7 +56,7 @@ _SIGS = {
                        _i, _i, _i, _vp]),
 }
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 3  # include/dm_sampler.h: DM_ABI_VERSION
+ABI_VERSION = 4  # include/dm_sampler.h: DM_ABI_VERSION
 CHUNK_FN = C.CFUNCTYPE(_vp, _vp, _i, _i)  # dm_chunk_fn
 
 

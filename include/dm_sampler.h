@@ -39,8 +39,10 @@ const char* dm_last_error(void);
 /* ABI version of this header; dm_version() returns the value the library was built with.  A binding checks
  * them for equality before it calls anything else (2: dm_unet_profile takes the length of its result arrays,
  * DM_K_COUNT grew, dm_sample accepts host pointers and sizes its workspace with dm_sample_workspace_bytes;
- * 3: dm_sample_chunked, the fused low-resolution kernel class, the any-geometry kernel classes). */
-#define DM_ABI_VERSION 3
+ * 3: dm_sample_chunked, the fused low-resolution kernel class, the any-geometry kernel classes;
+ * 4: dm_sample's workspace holds one carve per parallel sub-batch chain (dm_sample_workspace_bytes grew for large batches),
+ *    dm_sample_branches, dm_stream_create / dm_stream_destroy). */
+#define DM_ABI_VERSION 4
 int dm_version(void);
 /* sha256 over the compiler flags and sources this library was built from (__graft_entry__.build_key); "unkeyed" for a
  * hand build.  build() compares it with the tree it runs in, so a library built with other flags is not reused. */
