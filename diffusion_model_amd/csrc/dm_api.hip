@@ -50,6 +50,7 @@ inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // Per-device facts, looked up once per device ordinal (function attributes and the CU count are
 // per device: a process may run models on several GPUs).
 constexpr int DM_MAX_DEVICES = 64;
+constexpr int DM_MAX_BRANCHES = 8;  // dm_sample's parallel sub-batch chains (sample_split): the default rule asks for 4, DM_SPLIT for up to 8
 inline int current_device() {
   int d = 0;
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= DM_MAX_DEVICES) d = 0;
@@ -609,8 +610,8 @@ struct dm_unet {
   size_t total;
   std::vector<GraphEntry> graphs;
   // dm_sample's parallel branches (sample_split): side streams and fork / join events, created on first use, per device
-  hipStream_t split_streams[DM_MAX_DEVICES][3] = {};
-  hipEvent_t split_events[DM_MAX_DEVICES][4] = {};
+  hipStream_t split_streams[DM_MAX_DEVICES][DM_MAX_BRANCHES - 1] = {};
+  hipEvent_t split_events[DM_MAX_DEVICES][DM_MAX_BRANCHES] = {};
 };
 
 namespace {
@@ -1608,13 +1609,14 @@ int dm_sampler_coefs(const float* acp, const float* acp_prev, const float* pv, i
 // Measured (tools/diag/r3_split_ab*.sh, DDIM-50, 32x32 C=64, same box, 1 -> 4 branches): B=128 -1.5 %, B=256 +11 %, B=512 +3.3 %,
 // B=1024 +2.6 % (two branches +3.2 %), B=2048 +1.3 %, B=8192 +0.8 %; ancestral-1000 B=256 +9 %, B=64 (two branches of 32) -4 %;
 // bf16 B=1024 +4.2 %; widened 64x64 C=256 B=256 +-0, with attention +2 %.  Hence: four branches once a branch still fills the
-// chip's workgroup slots with its largest layer (>= 64 images of 32x32), none below.  DM_SPLIT = k forces k (read per call).
+// chip's workgroup slots with its largest layer (>= 64 images of 32x32), none below.  Eight branches lose against four at every size
+// (B=1024 -4 %, B=512 -10 %: the process has four hardware queues).  DM_SPLIT = k forces k <= 8 (read per call).
 static int sample_split(const dm_unet* m, int B, int H, int W, int guided) {
   const char* env = getenv("DM_SPLIT");
   const int forced = env ? atoi(env) : 0;
   if (B < 2) return 1;
   int k = forced > 0 ? forced : ((size_t)B * H * W >= ((size_t)256 << 10) ? 4 : 1);
-  if (k > 4) k = 4;
+  if (k > DM_MAX_BRANCHES) k = DM_MAX_BRANCHES;
   while (k > 1 && B % k) --k;
   (void)m;
   return k < 1 ? 1 : k;
@@ -1679,7 +1681,7 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
   const int Bk = B / NS;                        // images per sub-batch (NS divides B)
   const int Bdk = Bd / NS;                      // its denoiser batch
   const size_t countk = count / NS;
-  Workspace wsub[4];
+  Workspace wsub[DM_MAX_BRANCHES];
   wsub[0] = carve(m, ws, Bdk, H, W, n, noise ? (size_t)S0 * countk : 0);
   for (int k = 1; k < NS; ++k) {
     wsub[k] = carve(m, reinterpret_cast<char*>(ws) + (size_t)k * wsub[0].bytes, Bdk, H, W, n, noise ? (size_t)S0 * countk : 0);
@@ -1689,7 +1691,7 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
   }
   const Workspace& w = wsub[0];
   if (ws_bytes < (size_t)NS * w.bytes) return fail("workspace too small: %zu < %zu bytes (dm_sample_workspace_bytes)", ws_bytes, (size_t)NS * w.bytes);
-  hipStream_t sk[4] = {s, nullptr, nullptr, nullptr};
+  hipStream_t sk[DM_MAX_BRANCHES] = {s};
   hipEvent_t* ev = nullptr;
   if (NS > 1) {
     const int dev = current_device();
@@ -1697,7 +1699,7 @@ int dm_sample_chunked(dm_unet* m, const float* packed, float* x, int B, int H, i
       if (!m->split_streams[dev][k - 1]) HIP_TRY(hipStreamCreateWithFlags(&m->split_streams[dev][k - 1], hipStreamNonBlocking));
       sk[k] = m->split_streams[dev][k - 1];
     }
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < DM_MAX_BRANCHES; ++k)
       if (!m->split_events[dev][k]) HIP_TRY(hipEventCreateWithFlags(&m->split_events[dev][k], hipEventDisableTiming));
     ev = m->split_events[dev];
   }
