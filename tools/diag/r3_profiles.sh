@@ -33,5 +33,9 @@ sq)
   timeout -s KILL 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_model -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-configs > $O/pmc_sq_model.json 2> $O/pmc_sq_model.err || exit 1
   timeout -s KILL 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_cfg1 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-configs --sampler ancestral --ddim-steps 100 --batch 64 > $O/pmc_sq_cfg1.json 2> $O/pmc_sq_cfg1.err || exit 1
   ;;
+sq4)
+  # the same counters over one bf16 + guidance pass (BASELINE configs[3])
+  timeout -s KILL 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_cfg4 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-configs --precision bf16 --cfg > $O/pmc_sq_cfg4.json 2> $O/pmc_sq_cfg4.err || exit 1
+  ;;
 esac
 echo done $1

@@ -132,8 +132,10 @@ for c, o in tcls.items():
     print(f"class {c:28s} {o['launches']:5d} launches  {o['hbm_read_bytes_per_launch']/1e6:8.1f} MB read {o['hbm_write_bytes_per_launch']/1e6:8.1f} MB written per launch")
 
 # ---- SQ counters per kernel (MFMA-busy share of SIMD cycles, vector instructions per MFMA)
-for tag in ("model", "cfg1"):
+for tag in ("model", "cfg1", "cfg4"):
     d = f"pmc_sq_{tag}"
+    if tag == "cfg4" and not glob.glob(os.path.join(SRC, d + ".json")):
+        continue  # (optional pass: r3_profiles.sh sq4)
     keys.add(bench_line(d + ".json")["build_key"])
     crow = list(csv.DictReader(open(one(d + "/*/*counter_collection.csv"))))
     trace = {r["Dispatch_Id"]: r for r in csv.DictReader(open(one(d + "/*/*kernel_trace.csv")))}
@@ -164,7 +166,8 @@ for tag in ("model", "cfg1"):
         r = res[k]
         print(f"{tag:6s} {k:44s} n={r['launches']:5d} {r['avg_us_under_pmc']:8.1f} us  busy {100*(r['mfma_busy_frac_of_simd_cycles'] or 0):5.1f}%  "
               f"valu/mfma {r['valu_non_mfma_per_mfma'] or 0:5.2f}  clk {r['kernel_clock_ghz_grbm'] or 0:4.2f} GHz")
-    cmd = ("DDIM-50, B=1024, fp32" if tag == "model" else "ancestral, first 100 of 1000 steps, B=64, fp32")
+    cmd = ("DDIM-50, B=1024, fp32" if tag == "model" else "DDIM-50, B=1024, bf16 + guidance (2,048-image denoiser batch)" if tag == "cfg4"
+           else "ancestral, first 100 of 1000 steps, B=64, fp32")
     json.dump({"source": "DM_SPLIT=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES "
                          "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE (tools/diag/r3_profiles.sh sq; one bench pass, " + cmd + "); all launches of a kernel summed; "
                          "busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)",
